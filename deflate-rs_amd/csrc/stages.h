@@ -1,0 +1,674 @@
+// stages.h -- the per-element stage functions of the MI355X DEFLATE encode path.
+//
+// The encode path of deflate-rs (one serial sliding-window loop, /root/reference/src/lz77.rs,
+// matching.rs, huffman_lengths.rs, ...) is re-cut here into data-parallel stages whose
+// per-element work lives in this header as inline functions.  The HIP kernels
+// (deflate_kernels.hip) call them from device code; tests/hostsim/ compiles the same
+// functions for the host to diff every intermediate against the CPU oracle without a GPU.
+// Nothing in here is a CPU fallback of the product: the product path only ever runs the
+// kernels.
+//
+// Stage map (DESIGN.md has the derivations):
+//   links   link[p]  = distance to the previous position with the same 15-bit 3-byte hash
+//                      (chained_hash_table.rs:55-62,118-158), 0 if none within 32768
+//   match   M[p]     = result of matching.rs:87-166 longest_match for prev_length = 0; the
+//                      parser applies the prev_length filter (it is only a filter, see
+//                      DESIGN.md "M is a pure function of the data")
+//   step    step(j)  = what the lazy / greedy / rle parser (lz77.rs:305-547, rle.rs:23-71)
+//                      emits when it is at position j with no pending match: a run of
+//                      literals, at most one match, and the next such "restart" position
+//   path    the true parse is the chain 0 -> next(0) -> next(next(0)) ...
+//   blocks  every 31744 tokens (output_writer.rs:19) -> histogram -> Huffman lengths
+//           (length_encode.rs:347-415) -> block type (huffman_lengths.rs:167-287) -> bits
+#ifndef MI355_DEFLATE_STAGES_H
+#define MI355_DEFLATE_STAGES_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MI355_HD __host__ __device__ __forceinline__
+#else
+#define MI355_HD inline
+#endif
+
+namespace mi355 {
+
+// ---- constants (reference file:line in comments) --------------------------
+enum : uint32_t {
+    WINDOW_SIZE = 32768,        // chained_hash_table.rs:1
+    MIN_MATCH = 3,              // huffman_table.rs:20
+    MAX_MATCH = 258,            // huffman_table.rs:21
+    TOO_FAR = 8192,             // lz77.rs:276
+    MAX_BUFFER_LENGTH = 31744,  // output_writer.rs:19
+    MAX_STORED_BLOCK_LENGTH = 32767,  // stored_block.rs:11
+    NUM_LL = 286,               // huffman_table.rs:14
+    NUM_DIST = 30,              // huffman_table.rs:10
+    END_OF_BLOCK = 256,         // huffman_table.rs:28
+    MAX_JUMP = 520,             // bound on next(j)-j: <=257 lazy deferrals + 258 match bytes
+    ZONE = 576,                 // entry zone of a segment (>= MAX_JUMP, multiple of 64)
+};
+
+enum ParseMode : uint32_t { MODE_GREEDY = 0, MODE_LAZY = 1, MODE_RLE = 2 };
+enum BlockType : uint32_t { BT_STORED = 0, BT_FIXED = 1, BT_DYNAMIC = 2 };
+
+// Token = LZValue (lzvalue.rs:42-76): litlen | distance << 16; distance 0 => literal.
+MI355_HD uint32_t tok_literal(uint32_t byte) { return byte; }
+MI355_HD uint32_t tok_match(uint32_t len, uint32_t dist) { return (len - MIN_MATCH) | (dist << 16); }
+MI355_HD uint32_t tok_cover(uint32_t t) { return (t >> 16) ? (t & 0xff) + MIN_MATCH : 1; }
+
+// M entry: len | dist << 16 (len 0 = nothing found; len may be 2, which the parsers ignore).
+MI355_HD uint32_t m_pack(uint32_t len, uint32_t dist) { return len | (dist << 16); }
+MI355_HD uint32_t m_len(uint32_t m) { return m & 0xffff; }
+MI355_HD uint32_t m_dist(uint32_t m) { return m >> 16; }
+
+// ---- hash (chained_hash_table.rs:55-62) --------------------------------------------------
+// Three rolling updates ((h << 5) ^ b) & 0x7fff leave exactly this function of 3 bytes.
+MI355_HD uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) { return ((a & 31u) << 10) ^ (b << 5) ^ c; }
+
+// Quirk Q1 (lz77.rs:628-638): when the first block fills inside the first window, the rolling
+// hash is re-warmed with data[0], data[1]; the next two inserted positions w, w+1 then hash
+// (b0,b1,d[w+2]) and (b1,d[w+2],d[w+3]).  `on` = 0 in the common case.
+struct HashOverride {
+    uint64_t pos;
+    uint32_t b0, b1;
+    uint32_t on;
+};
+
+template <class Bytes>
+MI355_HD uint32_t position_hash(const Bytes& by, uint64_t p, const HashOverride& ov) {
+    uint32_t a = by(p), b = by(p + 1), c = by(p + 2);
+    if (ov.on) {
+        if (p == ov.pos) {
+            a = ov.b0;
+            b = ov.b1;
+        } else if (p == ov.pos + 1) {
+            a = ov.b1;
+        }
+    }
+    return hash3(a, b, c);
+}
+
+MI355_HD uint32_t ctz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(x);
+#else
+    return (uint32_t)__builtin_ctz(x);
+#endif
+}
+
+// ---- match (matching.rs:87-166 with prev_length = 0) -------------------------------------
+// `W` gives unaligned little-endian 4-byte loads and u16 links in one index space (window
+// coordinates on the GPU, absolute on the host).  p = index of the searched position,
+// max_len = min(N - P, 258) (matching.rs:112), checks = max_hash_checks.  If checks_q != 0 the
+// state after checks_q iterations is also reported (lz77.rs:351-355: the reduced budget used
+// when prev_length >= 32).  Iterations that end the chain count like the reference's do.
+template <class W>
+MI355_HD void match_walk(const W& w, uint32_t p, uint32_t max_len, uint32_t checks, uint32_t checks_q,
+                         uint32_t* out_m, uint32_t* out_mq) {
+    uint32_t best = 1, best_d = 0;
+    uint32_t cand = p;
+    uint32_t probe = w.load32(p) & 0xffffu;  // bytes best-1, best of P
+    uint32_t mq = 0;
+    bool have_q = (checks_q == 0);
+    for (uint32_t i = 0; i < checks; i++) {
+        if (!have_q && i == checks_q) {
+            mq = m_pack(best_d ? best : 0, best_d);
+            have_q = true;
+        }
+        uint32_t d = w.link(cand);
+        if (d == 0) break;                     // chain end (matching.rs:127, self loop / older)
+        if (d > cand) break;                   // cannot happen in a well-formed table
+        cand -= d;
+        if (p - cand > WINDOW_SIZE) break;     // current_head < limit (matching.rs:102-106,127)
+        if ((w.load32(cand + best - 1) & 0xffffu) == probe) {  // matching.rs:141-143
+            uint32_t len = 0;                  // get_match_length matching.rs:67-72
+            while (len < max_len) {
+                uint32_t x = w.load32(p + len) ^ w.load32(cand + len);
+                if (x) {
+                    len += ctz32(x) >> 3;
+                    break;
+                }
+                len += 4;
+            }
+            if (len > max_len) len = max_len;
+            if (len > best) {                  // matching.rs:149-156
+                best = len;
+                best_d = p - cand;
+                if (len == max_len) break;
+                probe = w.load32(p + best - 1) & 0xffffu;
+            }
+        }
+    }
+    uint32_t m = m_pack(best_d ? best : 0, best_d);
+    if (!have_q) mq = m;
+    *out_m = m;
+    *out_mq = mq;
+}
+
+// ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------
+// R[p] = number of bytes from p equal to data[p-1], capped at 258 and at the end of input; 0 if
+// p == 0 or data[p] != data[p-1].
+template <class Bytes>
+MI355_HD uint32_t rle_run(const Bytes& by, uint64_t p, uint64_t n) {
+    if (p == 0) return 0;
+    uint32_t prev = by(p - 1);
+    uint64_t cap = n - p < (uint64_t)MAX_MATCH ? n - p : (uint64_t)MAX_MATCH;
+    uint32_t c = 0;
+    while (c < cap && by(p + c) == prev) c++;
+    return c;
+}
+
+// ---- the parser as a restart transducer ---------------------------------------------------
+struct ParseCfg {
+    uint32_t mode;           // ParseMode
+    uint32_t checks;         // max_hash_checks
+    uint32_t lazy_lt;        // lazy_if_less_than (already clamped to 32768, deflate_state.rs:105)
+    uint32_t use_quarter;    // 1 if a second table with checks>>2 exists (checks>>2 != checks
+                             // can matter only when lazy_lt > 32)
+};
+
+struct Step {
+    uint32_t nlit;   // literals at j, j+1, ..., j+nlit-1
+    uint32_t mlen;   // 0 = no match in this step; else match at j+nlit
+    uint32_t mdist;
+    uint32_t adv;    // next restart position - j  (1..MAX_JUMP)
+};
+
+// lz77.rs:275-278
+MI355_HD bool match_too_far(uint32_t len, uint32_t dist) { return len == MIN_MATCH && dist > TOO_FAR; }
+
+// One restart step.  `M(p)` / `Mq(p)` read the match tables (full budget / quarter budget);
+// in MODE_RLE `M(p)` reads the run table.  j < n.
+//
+// Lazy (lz77.rs:305-486): at a position with no usable pending match the parser's future
+// depends only on the position.  It emits literal(j) if nothing (>= 3, not too far) is found
+// at j; otherwise it defers: as long as the match at a+1 is strictly longer (the prev_length
+// filter matching.rs:110,161), a becomes a literal; the chain ends by emitting the pending
+// match when it is not beaten, when it is >= lazy_if_less_than (lz77.rs:374-377: no lookahead),
+// or when a+1 has no hash byte (lz77.rs:442-468).
+template <class MT>
+MI355_HD Step parse_step(const MT& M, const MT& Mq, uint64_t j, uint64_t n, const ParseCfg& cfg) {
+    Step s;
+    s.nlit = 0;
+    s.mlen = 0;
+    s.mdist = 0;
+    s.adv = 1;
+    if (cfg.mode == MODE_RLE) {  // rle.rs:46-69
+        uint32_t r = (uint32_t)M(j);
+        if (r >= MIN_MATCH) {
+            s.mlen = r;
+            s.mdist = 1;
+            s.adv = r;
+        } else {
+            s.nlit = 1;
+        }
+        return s;
+    }
+    bool hashable = j + 2 < n;  // lz77.rs:294-301: a position has a hash byte iff p+2 < len
+    if (!hashable) {            // lz77.rs:470-482 / :539-544: the last two bytes are literals
+        s.nlit = 1;
+        return s;
+    }
+    uint32_t m = (uint32_t)M(j);
+    uint32_t L = m_len(m), D = m_dist(m);
+    if (L < MIN_MATCH || match_too_far(L, D)) {  // lz77.rs:370-372, :512
+        s.nlit = 1;
+        return s;
+    }
+    if (cfg.mode == MODE_GREEDY) {  // lz77.rs:512-534
+        s.mlen = L;
+        s.mdist = D;
+        s.adv = L;
+        return s;
+    }
+    uint64_t a = j;
+    for (;;) {
+        if (L >= cfg.lazy_lt) break;   // ignore_next (lz77.rs:374-377,380-386)
+        if (a + 1 + 2 >= n) break;     // a+1 has no hash byte (lz77.rs:442-468)
+        uint32_t m2 = (cfg.use_quarter && L >= 32) ? (uint32_t)Mq(a + 1) : (uint32_t)M(a + 1);  // lz77.rs:351-355
+        uint32_t L2 = m_len(m2);
+        if (L2 > L) {                  // strictly better (matching.rs:161); cannot be too_far (L2 >= 4)
+            s.nlit++;                  // lz77.rs:430-434: the previous byte becomes a literal
+            a++;
+            L = L2;
+            D = m_dist(m2);
+            continue;
+        }
+        break;                         // lz77.rs:388-429: the pending match wins
+    }
+    s.mlen = L;
+    s.mdist = D;
+    s.adv = s.nlit + L;
+    return s;
+}
+
+// ---- symbol coding (huffman_table.rs:45-194), arithmetic instead of lookup tables ---------
+MI355_HD uint32_t ilog2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
+
+// stored length s = len-3 -> code index 0..28, extra bit count and value (RFC 1951 3.2.5)
+MI355_HD void length_symbol(uint32_t s, uint32_t* code, uint32_t* nbits, uint32_t* value) {
+    if (s < 8) {
+        *code = s;
+        *nbits = 0;
+        *value = 0;
+    } else if (s == 255) {
+        *code = 28;
+        *nbits = 0;
+        *value = 0;
+    } else {
+        uint32_t k = ilog2(s);  // 3..7
+        *code = 4 * (k - 1) + ((s >> (k - 2)) & 3);
+        *nbits = k - 2;
+        *value = s & ((1u << (k - 2)) - 1);
+    }
+}
+// distance 1..32768 -> code 0..29, extra bit count and value
+MI355_HD void distance_symbol(uint32_t dist, uint32_t* code, uint32_t* nbits, uint32_t* value) {
+    uint32_t d = dist - 1;
+    if (d < 4) {
+        *code = d;
+        *nbits = 0;
+        *value = 0;
+    } else {
+        uint32_t k = ilog2(d);  // 2..14
+        *code = 2 * k + ((d >> (k - 1)) & 1);
+        *nbits = k - 1;
+        *value = d & ((1u << (k - 1)) - 1);
+    }
+}
+MI355_HD uint32_t length_extra_bits_of_code(uint32_t c) {  // LENGTH_EXTRA_BITS_LENGTH huffman_table.rs:45-47
+    return (c < 8 || c == 28) ? 0 : (c - 4) >> 2;
+}
+MI355_HD uint32_t distance_extra_bits_of_code(uint32_t c) {  // huffman_table.rs:120-126
+    uint32_t k = c >> 1;
+    return k ? k - 1 : 0;
+}
+MI355_HD uint32_t fixed_ll_length(uint32_t sym) {  // FIXED_CODE_LENGTHS huffman_table.rs:32-42
+    return sym < 144 ? 8 : sym < 256 ? 9 : sym < 280 ? 7 : 8;
+}
+
+// bit_reverse.rs:3-10
+MI355_HD uint32_t reverse_bits16(uint32_t n, uint32_t length) {
+    n = ((n & 0xaaaa) >> 1) | ((n & 0x5555) << 1);
+    n = ((n & 0xcccc) >> 2) | ((n & 0x3333) << 2);
+    n = ((n & 0xf0f0) >> 4) | ((n & 0x0f0f) << 4);
+    n = ((n & 0xff00) >> 8) | ((n & 0x00ff) << 8);
+    return (n & 0xffff) >> (16 - length);
+}
+
+// ---- Huffman code lengths (length_encode.rs:218-415) --------------------------------------
+// `nodes` holds the used symbols sorted ascending by (freq, symbol) -- identical to the
+// reference's stable sort by freq (length_encode.rs:386).  value[] is overwritten.
+struct HuffNode {
+    uint32_t value;
+    uint32_t symbol;
+};
+
+// In-place Moffat-Katajainen, the miniz length limiter and the reversed hand-out
+// (length_encode.rs:218-278, 290-327, 392-408).  lengths[] must be zeroed by the caller for
+// all symbols; n >= 2.
+template <class NodeArr, class LenArr>
+MI355_HD void huff_lengths_sorted(NodeArr& leaves, uint32_t n, uint32_t max_len, LenArr& lengths) {
+    // step_1 :218-247
+    {
+        uint32_t root = 0, leaf = 2;
+        leaves[0].value += leaves[1].value;
+        for (uint32_t next = 1; next + 1 < n; next++) {
+            if (leaf >= n || leaves[root].value < leaves[leaf].value) {
+                leaves[next].value = leaves[root].value;
+                leaves[root].value = next;
+                root++;
+            } else {
+                leaves[next].value = leaves[leaf].value;
+                leaf++;
+            }
+            if (leaf >= n || (root < next && leaves[root].value < leaves[leaf].value)) {
+                leaves[next].value += leaves[root].value;
+                leaves[root].value = next;
+                root++;
+            } else {
+                leaves[next].value += leaves[leaf].value;
+                leaf++;
+            }
+        }
+    }
+    // step_2 :249-278
+    {
+        leaves[n - 2].value = 0;
+        for (uint32_t t = n - 2; t-- > 0;) leaves[t].value = leaves[leaves[t].value].value + 1;
+        uint32_t available = 1, used = 0, depth = 0;
+        int32_t root = (int32_t)n - 2, next = (int32_t)n - 1;
+        while (available > 0) {
+            while (root >= 0 && leaves[root].value == depth) {
+                used++;
+                root--;
+            }
+            while (available > used) {
+                leaves[next].value = depth;
+                next--;
+                available--;
+            }
+            available = 2 * used;
+            depth++;
+            used = 0;
+        }
+    }
+    // depth histogram :392-395 and enforce_max_code_lengths :290-327
+    uint32_t num_codes[33];
+    for (int i = 0; i < 33; i++) num_codes[i] = 0;
+    for (uint32_t i = 0; i < n; i++) num_codes[leaves[i].value < 32 ? leaves[i].value : 32]++;
+    {
+        uint32_t above = 0;
+        for (uint32_t i = max_len + 1; i < 33; i++) above += num_codes[i];
+        num_codes[max_len] += above;
+        uint32_t total = 0;
+        for (uint32_t i = max_len; i >= 1; i--) total += num_codes[i] << (max_len - i);
+        while (total != (1u << max_len)) {
+            num_codes[max_len]--;
+            for (uint32_t i = max_len - 1; i >= 1; i--) {
+                if (num_codes[i] != 0) {
+                    num_codes[i]--;
+                    num_codes[i + 1] += 2;
+                    break;
+                }
+            }
+            total--;
+        }
+    }
+    // hand out lengths shortest first, walking the sorted leaves from the end :402-408
+    uint32_t li = n;
+    for (uint32_t i = 1; i <= max_len; i++)
+        for (uint32_t k = 0; k < num_codes[i]; k++) {
+            li--;
+            lengths[leaves[li].symbol] = (uint8_t)i;
+        }
+}
+
+// ---- run-length coding of the code lengths (length_encode.rs:82-155) ----------------------
+// Output symbol = kind << 8 | value; kind 0 literal length, 1 copy-previous (sym 16),
+// 2 zeros 3..10 (sym 17), 3 zeros 11..138 (sym 18).  freqs[19] must be zeroed by the caller.
+MI355_HD uint32_t el_symbol_index(uint32_t e) {
+    uint32_t k = e >> 8;
+    return k == 0 ? (e & 0xff) : 15 + k;
+}
+MI355_HD bool not_max_repetitions(uint32_t l, uint32_t repeats) { return (l == 0 && repeats < 138) || repeats < 6; }
+
+template <class LenArr, class OutArr, class FreqArr>
+MI355_HD uint32_t encode_lengths_rle(const LenArr& lengths, uint32_t n_len, OutArr& out, FreqArr& freqs) {
+    uint32_t n_out = 0;
+    uint32_t repeat = 0;
+    uint32_t prev = (~(uint32_t)lengths[0]) & 0xff;
+    uint32_t idx = 0;
+#define MI355_EL_PUSH(e)                 \
+    do {                                 \
+        uint32_t e__ = (e);              \
+        freqs[el_symbol_index(e__)]++;   \
+        out[n_out++] = (uint16_t)e__;    \
+    } while (0)
+    while (idx < n_len) {
+        uint32_t n = idx;
+        uint32_t l = lengths[idx++];
+        bool peek_none = idx >= n_len;
+        if (l == prev && not_max_repetitions(l, repeat)) repeat++;
+        if (l != prev || peek_none || !not_max_repetitions(l, repeat)) {
+            if (repeat >= 3) {
+                uint32_t kind = prev == 0 ? (repeat <= 10 ? 2u : 3u) : 1u;  // from_prev_and_repeat :19-31
+                MI355_EL_PUSH((kind << 8) | repeat);
+                repeat = 0;
+                if (l != prev) {
+                    if (l != 0 || peek_none) {
+                        MI355_EL_PUSH(l);
+                        repeat = 0;
+                    } else {
+                        repeat = 1;
+                    }
+                }
+            } else {
+                uint32_t extra_skip = (peek_none && l == prev) ? 1 : 0;
+                uint32_t skip = n + extra_skip - repeat;
+                uint32_t extra = (l != 0 || peek_none) ? 1 : 0;
+                uint32_t take = repeat + extra;
+                for (uint32_t k = 0; k < take && skip + k < n_len; k++) MI355_EL_PUSH(lengths[skip + k]);
+                repeat = 1 - extra;
+            }
+        }
+        prev = l;
+    }
+#undef MI355_EL_PUSH
+    return n_out;
+}
+
+// ---- canonical codes (huffman_table.rs:232-278) -------------------------------------------
+// codes[i] for lengths[i] != 0, bit-reversed for LSB-first emission.
+template <class LenArr, class CodeArr>
+MI355_HD void canonical_codes(const LenArr& lengths, uint32_t n, CodeArr& codes) {
+    uint32_t counts[16];
+    for (int i = 0; i < 16; i++) counts[i] = 0;
+    uint32_t max_length = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t l = lengths[i];
+        if (l) counts[l]++;
+        if (l > max_length) max_length = l;
+    }
+    uint32_t next_code[17];
+    uint32_t code = 0;
+    next_code[0] = 0;
+    for (uint32_t bits = 1; bits <= max_length; bits++) {
+        code = ((code + counts[bits - 1]) << 1) & 0xffff;
+        next_code[bits] = code;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t l = lengths[i];
+        if (l) {
+            codes[i] = (uint16_t)reverse_bits16(next_code[l], l);
+            next_code[l] = (next_code[l] + 1) & 0xffff;
+        }
+    }
+}
+
+// ---- per-block header (what one wave computes for one block) ------------------------------
+// HUFFMAN_LENGTH_ORDER huffman_lengths.rs:27-29
+MI355_HD uint32_t hclen_order(uint32_t i) {
+    const uint8_t o[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    return o[i];
+}
+
+struct BlockHeader {
+    uint8_t ll_len[288];
+    uint8_t d_len[32];
+    uint8_t cl_len[19];
+    uint8_t pad0;
+    uint16_t enc[320];      // run-length coded ll ++ dist lengths
+    uint32_t n_enc;
+    uint32_t n_ll;          // HLIT + 257
+    uint32_t n_d;           // HDIST + 1
+    uint32_t used_hclens;   // HCLEN + 4
+    uint64_t dyn_bits;      // what a dynamic block really takes, without the 3 block bits
+    uint64_t dyn_est;       // the reference's estimate (huffman_lengths.rs:257-263); it prices
+                            // symbol 16 at 3 extra bits (:50-56) although 2 are written (:343)
+    uint64_t static_est;    // the reference's estimate, Q12 bias included (:244-266)
+    uint64_t fixed_bits;    // what a fixed block really takes, without the 3 block bits
+};
+
+// stored_padding huffman_lengths.rs:113-124 and stored_length :132-143
+MI355_HD uint64_t stored_padding(uint32_t pending_bits) {
+    uint32_t free_space = 8 - pending_bits;
+    return free_space >= 3 ? free_space - 3 : 8 - (3 - free_space);
+}
+MI355_HD uint64_t stored_length_bits(uint64_t input_bytes) {
+    uint64_t num_blocks = (input_bytes - 1) / MAX_STORED_BLOCK_LENGTH + 1;
+    return (input_bytes + 4 * num_blocks + (num_blocks - 1)) * 8;
+}
+
+// Sort helper for the host / single-lane path: ascending by (value, symbol).
+template <class NodeArr>
+MI355_HD void sort_nodes(NodeArr& a, uint32_t n) {
+    for (uint32_t i = 1; i < n; i++) {
+        HuffNode x = a[i];
+        uint32_t j = i;
+        while (j > 0 && (a[j - 1].value > x.value || (a[j - 1].value == x.value && a[j - 1].symbol > x.symbol))) {
+            a[j] = a[j - 1];
+            j--;
+        }
+        a[j] = x;
+    }
+}
+
+// in_place_lengths length_encode.rs:347-415 for one alphabet: freqs[0..n) -> lengths[0..n_total)
+// (all n_total entries are zeroed first, :355-357).  `scratch` needs n entries.
+template <class FreqArr, class LenArr, class NodeArr>
+MI355_HD void huff_lengths(const FreqArr& freqs, uint32_t n, uint32_t n_total, uint32_t max_len, LenArr& lengths,
+                           NodeArr& scratch) {
+    for (uint32_t i = 0; i < n_total; i++) lengths[i] = 0;
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (freqs[i] > 0) {
+            scratch[m].value = freqs[i];
+            scratch[m].symbol = i;
+            m++;
+        }
+    if (m == 0) return;
+    if (m == 1) {
+        lengths[scratch[0].symbol] = 1;
+        return;
+    }
+    sort_nodes(scratch, m);
+    huff_lengths_sorted(scratch, m, max_len, lengths);
+}
+
+// gen_huffman_lengths huffman_lengths.rs:167-287 minus the block-type choice (which needs the
+// bit phase and is made by plan_block).  ll_freq[286] (EOB already counted), d_freq[30].
+template <class FreqArr, class NodeArr>
+MI355_HD void build_block_header(const FreqArr& ll_freq, const FreqArr& d_freq, BlockHeader& h, NodeArr& scratch) {
+    // remove_trailing_zeroes :44-47
+    uint32_t n_ll = NUM_LL;
+    while (n_ll > 257 && ll_freq[n_ll - 1] == 0) n_ll--;
+    uint32_t n_d = NUM_DIST;
+    while (n_d > 1 && d_freq[n_d - 1] == 0) n_d--;
+    huff_lengths(ll_freq, n_ll, 288, 15, h.ll_len, scratch);
+    huff_lengths(d_freq, n_d, 32, 15, h.d_len, scratch);
+    h.n_ll = n_ll;
+    h.n_d = n_d;
+    // chained lengths :212-218
+    uint8_t chain[320];
+    for (uint32_t i = 0; i < n_ll; i++) chain[i] = h.ll_len[i];
+    for (uint32_t i = 0; i < n_d; i++) chain[n_ll + i] = h.d_len[i];
+    uint32_t cl_freq[19];
+    for (int i = 0; i < 19; i++) cl_freq[i] = 0;
+    h.n_enc = encode_lengths_rle(chain, n_ll + n_d, h.enc, cl_freq);
+    huff_lengths(cl_freq, 19, 19, 7, h.cl_len, scratch);
+    uint32_t used = 19;  // :230-235
+    while (used > 0 && h.cl_len[hclen_order(used - 1)] == 0) used--;
+    h.used_hclens = used;
+    // costs :241-266
+    uint64_t d_ll = 0, s_ll = 0, f_ll = 0;
+    for (uint32_t c = 0; c < n_ll; c++) {
+        uint64_t f = ll_freq[c];
+        uint64_t extra = c >= 257 ? length_extra_bits_of_code(c - 257) : 0;
+        d_ll += f * (h.ll_len[c] + extra);
+        s_ll += f * (fixed_ll_length(c) + extra);
+    }
+    f_ll = s_ll;
+    uint64_t d_d = 0, s_d = 0, f_d = 0;
+    for (uint32_t c = 0; c < n_d; c++) {
+        uint64_t f = d_freq[c];
+        uint64_t extra = distance_extra_bits_of_code(c);
+        d_d += f * (h.d_len[c] + extra);
+        s_d += f * (fixed_ll_length(c) + extra);  // Q12: the ll table is used for distances too
+        f_d += f * (5 + extra);
+    }
+    uint64_t table = 0, table_real = 0;  // calculate_huffman_length :59-68
+    for (uint32_t i = 0; i < 19; i++) {
+        uint64_t extra = (i == 16 || i == 17) ? 3 : (i == 18 ? 7 : 0);
+        uint64_t extra_real = i == 16 ? 2 : extra;  // write_huffman_lengths :343
+        table += (uint64_t)cl_freq[i] * (h.cl_len[i] + extra);
+        table_real += (uint64_t)cl_freq[i] * (h.cl_len[i] + extra_real);
+    }
+    h.dyn_est = d_ll + d_d + table + (uint64_t)used * 3 + 5 + 5 + 4;
+    h.dyn_bits = d_ll + d_d + table_real + (uint64_t)used * 3 + 5 + 5 + 4;
+    h.static_est = s_ll + s_d;
+    h.fixed_bits = f_ll + f_d;
+}
+
+// ---- block plan (compress.rs:157-246, huffman_lengths.rs:179,269-286) ---------------------
+struct BlockPlan {
+    uint32_t btype;
+    uint32_t bfinal;
+    uint64_t bit_start;   // first header bit
+    uint64_t bit_len;     // total bits of the block including the 3 header bits and padding
+};
+
+// Bits a stored block sequence occupies when it starts at bit phase `phase` (0..7):
+// stored_block.rs:13-40, compress.rs:59-77.  Every piece: 3 header bits, pad to a byte, LEN,
+// NLEN, payload.
+MI355_HD uint64_t stored_total_bits(uint64_t nbytes, uint32_t phase) {
+    uint64_t bits = 0;
+    uint64_t left = nbytes;
+    uint32_t ph = phase;
+    do {
+        uint64_t piece = left < (uint64_t)MAX_STORED_BLOCK_LENGTH ? left : (uint64_t)MAX_STORED_BLOCK_LENGTH;
+        uint64_t hdr = 3 + ((8 - ((ph + 3) & 7)) & 7);
+        bits += hdr + 32 + piece * 8;
+        ph = 0;
+        left -= piece;
+    } while (left > 0);
+    return bits;
+}
+
+// Decide one block.  in_bytes = bytes its tokens cover, ntok unused except for clarity.
+MI355_HD void plan_block(const BlockHeader& h, uint64_t in_bytes, bool is_last, uint64_t bit_pos, BlockPlan* out) {
+    uint32_t btype;
+    if (in_bytes <= 4) {  // huffman_lengths.rs:179-181
+        btype = BT_FIXED;
+    } else {
+        uint64_t stored = stored_length_bits(in_bytes) + stored_padding((uint32_t)(bit_pos & 7));  // :269
+        uint64_t used = h.dyn_est < h.static_est ? h.dyn_est : h.static_est;
+        if (stored < used) used = stored;
+        if (used == h.static_est)
+            btype = BT_FIXED;  // :277-286 (Q5)
+        else if (used == stored)
+            btype = BT_STORED;
+        else
+            btype = BT_DYNAMIC;
+    }
+    out->btype = btype;
+    out->bfinal = is_last ? 1 : 0;
+    out->bit_start = bit_pos;
+    if (btype == BT_FIXED)
+        out->bit_len = 3 + h.fixed_bits;
+    else if (btype == BT_DYNAMIC)
+        out->bit_len = 3 + h.dyn_bits;
+    else
+        out->bit_len = stored_total_bits(in_bytes, (uint32_t)(bit_pos & 7));
+}
+
+// Bits of one token under a code table: returns the concatenated LSB-first bit string (<= 48
+// bits) and its length (encoder_state.rs:58-83).
+template <class LLCodes, class LLLens, class DCodes, class DLens>
+MI355_HD uint64_t token_bits(uint32_t tok, const LLCodes& llc, const LLLens& lll, const DCodes& dc, const DLens& dl,
+                             uint32_t* nbits) {
+    uint32_t dist = tok >> 16;
+    if (dist == 0) {
+        uint32_t b = tok & 0xff;
+        *nbits = lll[b];
+        return llc[b];
+    }
+    uint32_t code, eb, ev;
+    length_symbol(tok & 0xff, &code, &eb, &ev);
+    uint32_t sym = 257 + code;
+    uint64_t bits = llc[sym];
+    uint32_t n = lll[sym];
+    bits |= (uint64_t)ev << n;
+    n += eb;
+    uint32_t dcode, deb, dev;
+    distance_symbol(dist, &dcode, &deb, &dev);
+    bits |= (uint64_t)dc[dcode] << n;
+    n += dl[dcode];
+    bits |= (uint64_t)dev << n;
+    n += deb;
+    *nbits = n;
+    return bits;
+}
+
+}  // namespace mi355
+#endif

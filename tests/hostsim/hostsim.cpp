@@ -1,0 +1,428 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE.  Runs the stage functions of
+// deflate-rs_amd/csrc/stages.h sequentially on the host, stage by stage and array by array
+// exactly as the HIP kernels are organised, so that the re-cut of the reference's serial loop
+// (pure match table -> restart path -> 31744-token blocks -> per-block Huffman -> bit plan)
+// can be diffed against the CPU oracle without a GPU.  It is never linked into the product
+// library.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../deflate-rs_amd/csrc/stages.h"
+
+using namespace mi355;
+
+namespace {
+
+struct HostBytes {
+    const uint8_t* d;
+    uint32_t operator()(uint64_t i) const { return d[i]; }
+};
+
+struct HostWin {  // absolute index space
+    const uint8_t* d;
+    const uint16_t* lk;
+    uint32_t load32(uint32_t i) const {
+        uint32_t v;
+        memcpy(&v, d + i, 4);
+        return v;
+    }
+    uint32_t link(uint32_t i) const { return lk[i]; }
+};
+
+struct MAcc {
+    const uint32_t* m;
+    uint32_t operator()(uint64_t i) const { return m[i]; }
+};
+
+struct Sim {
+    std::vector<uint8_t> in;  // padded with 16 zero bytes
+    uint64_t n;
+    ParseCfg cfg;
+    std::vector<uint16_t> link;
+    std::vector<uint32_t> M, Mq;
+    std::vector<uint16_t> adv;
+    std::vector<uint32_t> tokens;
+    std::vector<uint64_t> tok_pos;
+    int hier_mismatch = 0;
+};
+
+void stage_links(Sim& s, const HashOverride& ov) {
+    s.link.assign(s.n + 1, 0);
+    std::vector<int64_t> head(32768, -1);
+    HostBytes by{s.in.data()};
+    for (uint64_t p = 0; p + 2 < s.n; p++) {
+        uint32_t h = position_hash(by, p, ov);
+        int64_t q = head[h];
+        s.link[p] = (q >= 0 && p - (uint64_t)q <= WINDOW_SIZE) ? (uint16_t)(p - (uint64_t)q) : 0;
+        head[h] = (int64_t)p;
+    }
+}
+
+void stage_match(Sim& s) {
+    s.M.assign(s.n + 1, 0);
+    s.Mq.assign(s.n + 1, 0);
+    if (s.cfg.mode == MODE_RLE) {
+        HostBytes by{s.in.data()};
+        for (uint64_t p = 0; p < s.n; p++) s.M[p] = rle_run(by, p, s.n);
+        return;
+    }
+    if (s.cfg.checks == 0) return;
+    HostWin w{s.in.data(), s.link.data()};
+    uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
+    for (uint64_t p = 0; p + 2 < s.n; p++) {
+        uint32_t max_len = (uint32_t)std::min<uint64_t>(s.n - p, MAX_MATCH);
+        uint32_t m, mq;
+        if (s.cfg.use_quarter && cq == 0) {
+            // budget >> 2 == 0: zero iterations -> nothing found
+            match_walk(w, (uint32_t)p, max_len, s.cfg.checks, 0, &m, &mq);
+            mq = 0;
+        } else {
+            match_walk(w, (uint32_t)p, max_len, s.cfg.checks, cq, &m, &mq);
+        }
+        s.M[p] = m;
+        s.Mq[p] = mq;
+    }
+}
+
+// direct serial walk of the restart path
+void stage_parse_direct(Sim& s) {
+    s.tokens.clear();
+    s.tok_pos.clear();
+    MAcc M{s.M.data()}, Mq{s.Mq.data()};
+    uint64_t j = 0;
+    while (j < s.n) {
+        Step st = parse_step(M, Mq, j, s.n, s.cfg);
+        for (uint32_t k = 0; k < st.nlit; k++) {
+            s.tokens.push_back(tok_literal(s.in[j + k]));
+            s.tok_pos.push_back(j + k);
+        }
+        if (st.mlen) {
+            s.tokens.push_back(tok_match(st.mlen, st.mdist));
+            s.tok_pos.push_back(j + st.nlit);
+        }
+        j += st.adv;
+    }
+}
+
+// The same path found the way the GPU finds it: adv[j] for every j, per-segment exit tables by
+// a right-to-left sweep, a tree of composed tables, then top-down entry resolution.
+void stage_parse_hier(Sim& s, uint32_t S, uint32_t G) {
+    MAcc M{s.M.data()}, Mq{s.Mq.data()};
+    uint64_t n = s.n;
+    s.adv.assign(n, 0);
+    for (uint64_t j = 0; j < n; j++) s.adv[j] = (uint16_t)parse_step(M, Mq, j, n, s.cfg).adv;
+    uint64_t K = (n + S - 1) / S;
+    if (K == 0) return;
+    // level 0: X[k][e] = first path position >= seg_end starting from seg_start + e
+    std::vector<std::vector<uint64_t>> levels_start;  // unit start per level
+    std::vector<std::vector<uint32_t>> tables;        // [unit * ZONE + e] = exit - unit_end
+    std::vector<uint64_t> unit_size;
+    {
+        std::vector<uint32_t> X(K * ZONE, 0);
+        std::vector<uint16_t> J(S);
+        for (uint64_t k = 0; k < K; k++) {
+            uint64_t a = k * S, b = std::min<uint64_t>(n, a + S);
+            for (uint64_t j = b; j-- > a;) {
+                uint64_t t = j + s.adv[j];
+                J[j - a] = (uint16_t)(t >= b ? t - b : J[t - a]);
+            }
+            for (uint32_t e = 0; e < ZONE; e++) X[k * ZONE + e] = (a + e < b) ? J[e] : (uint32_t)(a + e - b);
+        }
+        tables.push_back(X);
+        unit_size.push_back(S);
+    }
+    // level up
+    while (tables.back().size() / ZONE > 1) {
+        const std::vector<uint32_t>& C = tables.back();
+        uint64_t csize = unit_size.back();
+        uint64_t nc = C.size() / ZONE;
+        uint64_t nu = (nc + G - 1) / G;
+        uint64_t usize = csize * G;
+        std::vector<uint32_t> X(nu * ZONE, 0);
+        for (uint64_t u = 0; u < nu; u++) {
+            uint64_t ustart = u * usize, uend = std::min<uint64_t>(n, ustart + usize);
+            for (uint32_t e = 0; e < ZONE; e++) {
+                uint64_t pos = ustart + e;
+                for (uint64_t c = u * G; c < std::min<uint64_t>(nc, (u + 1) * G); c++) {
+                    uint64_t cstart = c * csize, cend = std::min<uint64_t>(n, cstart + csize);
+                    if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
+                }
+                X[u * ZONE + e] = (uint32_t)(pos - uend);
+            }
+        }
+        tables.push_back(X);
+        unit_size.push_back(usize);
+    }
+    // top-down: E[level][unit] = first path position >= unit start
+    std::vector<uint64_t> Ecur(1, 0);
+    for (size_t lv = tables.size() - 1; lv-- > 0;) {
+        const std::vector<uint32_t>& C = tables[lv];
+        uint64_t csize = unit_size[lv];
+        uint64_t nc = C.size() / ZONE;
+        std::vector<uint64_t> En(nc, 0);
+        for (uint64_t u = 0; u < Ecur.size(); u++) {
+            uint64_t pos = Ecur[u];
+            for (uint64_t c = u * G; c < std::min<uint64_t>(nc, (u + 1) * G); c++) {
+                uint64_t cstart = c * csize, cend = std::min<uint64_t>(n, cstart + csize);
+                if (pos < cstart) pos = cstart;  // cannot happen; path positions only grow
+                En[c] = pos;
+                if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
+            }
+        }
+        Ecur = En;
+    }
+    // emit per segment from its entry, compare with the direct walk
+    std::vector<uint32_t> toks;
+    for (uint64_t k = 0; k < K; k++) {
+        uint64_t b = std::min<uint64_t>(n, (k + 1) * S);
+        uint64_t j = Ecur[k];
+        while (j < b) {
+            Step st = parse_step(M, Mq, j, n, s.cfg);
+            for (uint32_t q = 0; q < st.nlit; q++) toks.push_back(tok_literal(s.in[j + q]));
+            if (st.mlen) toks.push_back(tok_match(st.mlen, st.mdist));
+            j += st.adv;
+        }
+    }
+    if (toks != s.tokens) s.hier_mismatch = 1;
+}
+
+struct BitSink {
+    std::vector<uint8_t>& out;
+    void put(uint64_t bitpos, uint64_t bits, uint32_t nbits) {
+        for (uint32_t i = 0; i < nbits; i++)
+            if ((bits >> i) & 1) out[(bitpos + i) >> 3] |= (uint8_t)(1u << ((bitpos + i) & 7));
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+struct hostsim_block {
+    uint32_t btype, bfinal, ntok;
+    uint64_t in_bytes, bit_start;
+};
+
+// returns 0 ok; -3 = reference would panic (Q13 slice out of range); fills *flags with bit0 =
+// Q1 override used, bit1 = Q13 shifted stored source used, bit2 = hierarchical path mismatch
+int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy_lt, uint32_t matching_type,
+                   uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t* flags, hostsim_block* blocks,
+                   uint64_t blocks_cap, uint64_t* n_blocks, uint32_t seg, uint32_t fan) {
+    Sim s;
+    s.n = n;
+    s.in.assign(in, in + n);
+    s.in.resize(n + 16, 0);
+    s.cfg.checks = checks;
+    s.cfg.lazy_lt = lazy_lt < 32768 ? lazy_lt : 32768;
+    s.cfg.mode = matching_type == 0 ? MODE_GREEDY : (checks == 0 ? MODE_RLE : MODE_LAZY);
+    s.cfg.use_quarter = (s.cfg.mode == MODE_LAZY && s.cfg.lazy_lt > 32) ? 1 : 0;
+    if (s.cfg.mode == MODE_LAZY && s.cfg.lazy_lt < 3) return -4;  // unsupported
+    *flags = 0;
+
+    HashOverride ov = {0, 0, 0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        if (s.cfg.mode != MODE_RLE && checks > 0) stage_links(s, ov);
+        stage_match(s);
+        stage_parse_direct(s);
+        if (pass == 1 || s.cfg.mode == MODE_RLE || checks == 0) break;
+        // Q1 (lz77.rs:628-638): did block 0 fill inside the first window with overlap == 0?
+        if (s.tokens.size() < MAX_BUFFER_LENGTH || n < 2) break;
+        uint32_t t = s.tokens[MAX_BUFFER_LENGTH - 1];
+        uint64_t tp = s.tok_pos[MAX_BUFFER_LENGTH - 1];
+        uint64_t lp, w;  // loop position at which the token was pushed; restart position
+        if (s.cfg.mode == MODE_LAZY) {
+            bool hashable_next = (tp + 1) + 2 < n;  // pushed in the normal branch of position tp+1
+            if (t >> 16) {
+                lp = tp + 1;
+                w = tp + tok_cover(t);
+            } else if (hashable_next) {
+                lp = tp + 1;
+                w = tp + 2;
+            } else {
+                lp = tp + 1;  // tail pushes: positions without hash byte; override is a no-op
+                w = tp + 1;
+            }
+        } else {
+            lp = tp;
+            w = tp + tok_cover(t);
+        }
+        if (lp < WINDOW_SIZE && w <= WINDOW_SIZE) {
+            ov.on = 1;
+            ov.pos = w;
+            ov.b0 = in[0];
+            ov.b1 = in[1];
+            *flags |= 1;
+            continue;
+        }
+        break;
+    }
+    if (seg) stage_parse_hier(s, seg, fan ? fan : 4);
+    if (s.hier_mismatch) *flags |= 4;
+
+    // blocks
+    uint64_t T = s.tokens.size();
+    uint64_t nb = T / MAX_BUFFER_LENGTH + 1;
+    *n_blocks = nb;
+    std::vector<BlockHeader> hdr(nb);
+    std::vector<BlockPlan> plan(nb);
+    std::vector<uint64_t> bstart(nb + 1);
+    for (uint64_t b = 0; b < nb; b++) {
+        uint64_t t0 = b * MAX_BUFFER_LENGTH;
+        bstart[b] = t0 < T ? s.tok_pos[t0] : n;
+    }
+    bstart[nb] = n;
+    std::vector<HuffNode> scratch(288);
+    uint64_t bitpos = 0;
+    std::vector<uint64_t> src_shift(nb, 0);
+    for (uint64_t b = 0; b < nb; b++) {
+        uint64_t t0 = b * MAX_BUFFER_LENGTH, t1 = std::min<uint64_t>(T, t0 + MAX_BUFFER_LENGTH);
+        uint32_t llf[NUM_LL] = {0}, df[NUM_DIST] = {0};
+        llf[END_OF_BLOCK] = 1;
+        for (uint64_t t = t0; t < t1; t++) {
+            uint32_t tk = s.tokens[t];
+            if (tk >> 16) {
+                uint32_t c, eb, ev;
+                length_symbol(tk & 0xff, &c, &eb, &ev);
+                llf[257 + c]++;
+                distance_symbol(tk >> 16, &c, &eb, &ev);
+                df[c]++;
+            } else {
+                llf[tk & 0xff]++;
+            }
+        }
+        const uint32_t* pl = llf;
+        const uint32_t* pd = df;
+        build_block_header(pl, pd, hdr[b], scratch);
+        uint64_t in_bytes = bstart[b + 1] - bstart[b];
+        plan_block(hdr[b], in_bytes, b + 1 == nb, bitpos, &plan[b]);
+        // Q13: a full block whose last value is a match crossing the end of a
+        // non-first window makes the reference slide before it reads the stored bytes.
+        if (plan[b].btype == BT_STORED && t1 - t0 == MAX_BUFFER_LENGTH) {
+            uint32_t tk = s.tokens[t1 - 1];
+            uint64_t tp = s.tok_pos[t1 - 1];
+            if (tk >> 16) {
+                uint64_t lp = (s.cfg.mode == MODE_LAZY) ? tp + 1 : tp;
+                uint64_t wdx = lp / WINDOW_SIZE;
+                uint64_t wend = (wdx + 1) * (uint64_t)WINDOW_SIZE;
+                uint64_t mend = tp + tok_cover(tk);
+                if (wdx >= 1 && mend > wend) {
+                    // after the slide the buffer holds [wdx*32768, min(n, wdx*32768 + 65794))
+                    uint64_t buf_end = std::min<uint64_t>(n, wdx * (uint64_t)WINDOW_SIZE + 65794);
+                    if (mend + WINDOW_SIZE > buf_end) return -3;
+                    src_shift[b] = WINDOW_SIZE;
+                    *flags |= 2;
+                }
+            }
+        }
+        bitpos += plan[b].bit_len;
+        if (b < blocks_cap) {
+            blocks[b].btype = plan[b].btype;
+            blocks[b].bfinal = plan[b].bfinal;
+            blocks[b].ntok = (uint32_t)(t1 - t0);
+            blocks[b].in_bytes = in_bytes;
+            blocks[b].bit_start = plan[b].bit_start;
+        }
+    }
+    uint64_t total_bytes = (bitpos + 7) / 8;
+    *out_len = total_bytes;
+    if (total_bytes > cap) return -2;
+    std::vector<uint8_t> o(total_bytes + 8, 0);
+    BitSink sink{o};
+    for (uint64_t b = 0; b < nb; b++) {
+        uint64_t t0 = b * MAX_BUFFER_LENGTH, t1 = std::min<uint64_t>(T, t0 + MAX_BUFFER_LENGTH);
+        uint64_t bp = plan[b].bit_start;
+        const BlockHeader& h = hdr[b];
+        if (plan[b].btype == BT_STORED) {
+            uint64_t src = bstart[b] + src_shift[b];
+            uint64_t left = bstart[b + 1] - bstart[b];
+            do {
+                uint64_t piece = std::min<uint64_t>(left, MAX_STORED_BLOCK_LENGTH);
+                bool last_piece = piece == left;
+                sink.put(bp, (plan[b].bfinal && last_piece) ? 1 : 0, 3);
+                bp += 3;
+                bp = (bp + 7) & ~7ull;
+                sink.put(bp, piece & 0xffff, 16);
+                sink.put(bp + 16, (~piece) & 0xffff, 16);
+                bp += 32;
+                for (uint64_t i = 0; i < piece; i++) o[(bp >> 3) + i] |= s.in[src + i];
+                bp += piece * 8;
+                src += piece;
+                left -= piece;
+            } while (left > 0);
+            continue;
+        }
+        uint16_t llc[288] = {0}, dc[32] = {0};
+        uint8_t lll[288], dl[32];
+        if (plan[b].btype == BT_FIXED) {
+            for (int i = 0; i < 288; i++) lll[i] = (uint8_t)fixed_ll_length(i);
+            for (int i = 0; i < 32; i++) dl[i] = 5;
+            sink.put(bp, plan[b].bfinal ? 3 : 2, 3);
+            bp += 3;
+        } else {
+            memcpy(lll, h.ll_len, 288);
+            memcpy(dl, h.d_len, 32);
+            sink.put(bp, plan[b].bfinal ? 5 : 4, 3);
+            bp += 3;
+            sink.put(bp, h.n_ll - 257, 5);
+            sink.put(bp + 5, h.n_d - 1, 5);
+            sink.put(bp + 10, h.used_hclens >= 4 ? h.used_hclens - 4 : 0, 4);
+            bp += 14;
+            for (uint32_t i = 0; i < h.used_hclens; i++) {
+                sink.put(bp, h.cl_len[hclen_order(i)], 3);
+                bp += 3;
+            }
+            uint16_t clc[19] = {0};
+            canonical_codes(h.cl_len, 19, clc);
+            for (uint32_t i = 0; i < h.n_enc; i++) {
+                uint32_t e = h.enc[i], kind = e >> 8, v = e & 0xff;
+                uint32_t sym = el_symbol_index(e);
+                sink.put(bp, clc[sym], h.cl_len[sym]);
+                bp += h.cl_len[sym];
+                if (kind == 1) {
+                    sink.put(bp, v - 3, 2);
+                    bp += 2;
+                } else if (kind == 2) {
+                    sink.put(bp, v - 3, 3);
+                    bp += 3;
+                } else if (kind == 3) {
+                    sink.put(bp, v - 11, 7);
+                    bp += 7;
+                }
+            }
+        }
+        canonical_codes(lll, 288, llc);
+        canonical_codes(dl, 32, dc);
+        for (uint64_t t = t0; t < t1; t++) {
+            uint32_t nb2;
+            uint64_t bits = token_bits(s.tokens[t], llc, lll, dc, dl, &nb2);
+            sink.put(bp, bits, nb2);
+            bp += nb2;
+        }
+        sink.put(bp, llc[END_OF_BLOCK], lll[END_OF_BLOCK]);
+        bp += lll[END_OF_BLOCK];
+        if (bp != plan[b].bit_start + plan[b].bit_len) return -5;  // plan/emit disagreement
+    }
+    memcpy(out, o.data(), total_bytes);
+    return 0;
+}
+
+// expose M for diffing: longest_match(prev_length=0) for every position
+int hostsim_match_table(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t* m_out) {
+    Sim s;
+    s.n = n;
+    s.in.assign(in, in + n);
+    s.in.resize(n + 16, 0);
+    s.cfg.checks = checks;
+    s.cfg.lazy_lt = 32;
+    s.cfg.mode = MODE_LAZY;
+    s.cfg.use_quarter = 0;
+    HashOverride ov = {0, 0, 0, 0};
+    stage_links(s, ov);
+    stage_match(s);
+    for (uint64_t i = 0; i < n; i++) m_out[i] = s.M[i];
+    return 0;
+}
+}
