@@ -1,0 +1,784 @@
+// deflate_kernels.hip -- gfx950 (MI355X) kernels of the DEFLATE encode path.
+//
+// One kernel per stage of stages.h; every kernel names the reference code it stands in for.
+// Layout of the per-encode workspace in HBM (n = input bytes, K = ceil(n / SEG) segments,
+// nb <= n / 31744 + 1 blocks):
+//   link   u16[n]      distance to the previous position with the same hash      2 B/byte
+//   M, Mq  u32[n]      longest_match(prev_length = 0) at full / quarter budget   4 (+4) B/byte
+//   adv    u16[n]      restart step length from every position                   2 B/byte
+//   J      u16[n]      scratch of the per-segment exit sweep                     2 B/byte
+//   X[l]   u32[K_l*ZONE]  exit tables per level, E[l] u32[K_l] entry positions
+//   tokbuf u32[K*SEG]  tokens per segment, dtok u32[T] tokens in stream order    4 + 4 B/byte
+//   per block: ll_freq u32[288], d_freq u32[32], BlockHeader, BlockPlan, bstart
+// All integer work; the bound is LDS/issue rate in k_match and HBM elsewhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stages.h"
+
+namespace mi355 {
+
+// ---- device-side accessors -----------------------------------------------------------------
+struct GBytes {  // bounds-checked global bytes (reads past the end give 0)
+    const uint8_t* d;
+    uint64_t n;
+    __device__ uint32_t operator()(uint64_t i) const { return i < n ? d[i] : 0u; }
+};
+struct GM {  // match / run table in global memory
+    const uint32_t* m;
+    __device__ uint32_t operator()(uint64_t i) const { return m[i]; }
+};
+struct LdsWin {  // the window of k_match: bytes and links in one window coordinate system
+    const uint8_t* by;
+    const uint16_t* lk;
+    __device__ uint32_t load32(uint32_t i) const {
+        uint32_t v;
+        __builtin_memcpy(&v, by + i, 4);  // gfx950 LDS takes the unaligned ds_read_b32
+        return v;
+    }
+    __device__ uint32_t link(uint32_t i) const { return lk[i]; }
+};
+
+// scalars shared between kernels of one encode
+struct DevScalars {
+    uint32_t T;            // tokens in the stream
+    uint32_t nb;           // blocks (T / 31744 + 1)
+    uint64_t total_bits;   // raw deflate bits
+    uint32_t b0_full;      // block 0 holds 31744 tokens
+    uint32_t b0_last_tok;  // its last token
+    uint32_t b0_last_pos;  // and where that token starts
+    uint32_t q13_hits;
+    uint32_t ref_panic;
+    uint32_t n_stored, n_fixed, n_dynamic;
+    uint32_t adler;
+    uint32_t pad;
+};
+
+constexpr uint32_t SEG = 1024;  // positions per level-0 segment
+constexpr uint32_t FAN = 32;    // children per unit in the table tree
+
+// ---------------------------------------------------------------------------------------------
+// k_links: chained_hash_table.rs:118-158 (add_hash_value) for every position, as "distance to
+// the most recent earlier position with the same hash".  One wave owns one 32 KiB epoch: it
+// replays the previous epoch to warm a 32768-entry last-occurrence table in LDS (64 KiB, u16
+// window-relative positions), then emits links for its own epoch.  Inside a 64-position batch
+// equal hashes are resolved with 15 ballots (peer mask), so the table is read once and written
+// once per batch without atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_links(const uint8_t* __restrict__ in, uint32_t n, uint16_t* __restrict__ link,
+                                              HashOverride ov) {
+    __shared__ uint16_t head[32768];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t c0 = (uint64_t)blockIdx.x * WINDOW_SIZE;
+    const int64_t base = (int64_t)c0 - WINDOW_SIZE;  // window-relative 0
+    for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0xFFFF;
+    __syncthreads();
+    GBytes by{in, n};
+    uint64_t start = base < 0 ? 0 : (uint64_t)base;
+    uint64_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;
+    for (uint64_t p0 = start; p0 < stop; p0 += 64) {
+        uint64_t p = p0 + lane;
+        bool active = p + 2 < n;
+        uint32_t h = active ? position_hash(by, p, ov) : 0;
+        uint64_t act = __ballot(active);
+        uint64_t peers = act;
+#pragma unroll
+        for (int b = 0; b < 15; b++) {
+            uint64_t bal = __ballot(active && ((h >> b) & 1));
+            peers &= ((h >> b) & 1) ? bal : ~bal;
+        }
+        uint64_t lower = peers & ((1ull << lane) - 1ull);
+        uint32_t rel = (uint32_t)((int64_t)p - base);  // 0..65535
+        uint32_t l = 0;
+        if (active) {
+            if (lower) {
+                l = lane - (63u - (uint32_t)__builtin_clzll(lower));
+            } else {
+                uint32_t stored = head[h];
+                if (stored < rel && rel - stored <= WINDOW_SIZE) l = rel - stored;
+            }
+        }
+        if (p >= c0 && p < n) link[p] = (uint16_t)l;
+        __syncthreads();
+        if (active && ((peers >> lane) >> 1) == 0) head[h] = (uint16_t)rel;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match: matching.rs:87-166 longest_match (prev_length = 0) for every position.  A workgroup
+// stages the 32 KiB history + its tile + 258 lookahead bytes and the links of the same range
+// in LDS (120 KiB) and each lane walks the chain of its own positions (match_walk).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t MT = 8192;                                // positions per tile
+constexpr uint32_t MTHREADS = 1024;
+constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // 41232, multiple of 16
+constexpr uint32_t MW_LINKS = WINDOW_SIZE + MT;
+
+__global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ in, uint32_t n,
+                                                    const uint16_t* __restrict__ link, uint32_t* __restrict__ M,
+                                                    uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
+                                                    int in_aligned4) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[MW_BYTES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_link[MW_LINKS];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t E = (uint64_t)blockIdx.x * MT;
+    const uint64_t wstart = E >= WINDOW_SIZE ? E - WINDOW_SIZE : 0;
+    uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_bytes);
+    for (uint32_t w = tid; w < MW_BYTES / 4; w += MTHREADS) {
+        uint64_t g = wstart + 4ull * w;
+        uint32_t v = 0;
+        if (in_aligned4 && g + 4 <= n) {
+            v = *reinterpret_cast<const uint32_t*>(in + g);
+        } else {
+            for (int b = 0; b < 4; b++)
+                if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
+        }
+        sb32[w] = v;
+    }
+    uint32_t* sl32 = reinterpret_cast<uint32_t*>(s_link);
+    for (uint32_t w = tid; w < MW_LINKS / 2; w += MTHREADS) {
+        uint64_t g = wstart + 2ull * w;
+        uint32_t v = 0;
+        if (g + 1 < n)
+            v = *reinterpret_cast<const uint32_t*>(link + g);  // wstart is even, link is 4-aligned
+        else if (g < n)
+            v = link[g];
+        sl32[w] = v;
+    }
+    __syncthreads();
+    LdsWin win{s_bytes, s_link};
+    for (uint32_t k = 0; k < MT / MTHREADS; k++) {
+        uint64_t p = E + tid + (uint64_t)k * MTHREADS;
+        if (p >= n) break;
+        uint32_t m = 0, mq = 0;
+        if (p + 2 < n) {
+            uint32_t max_len = n - p < MAX_MATCH ? (uint32_t)(n - p) : (uint32_t)MAX_MATCH;
+            match_walk(win, (uint32_t)(p - wstart), max_len, checks, checks_q, &m, &mq);
+        }
+        M[p] = m;
+        if (Mq) Mq[p] = mq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rle: rle.rs:13-18 get_match_length_rle for every position: R[p] = run of data[p-1]
+// starting at p, capped at 258 and at the end of input.  Each lane owns 16 consecutive
+// positions: one forward scan of at most 258 bytes past its chunk, then a backward recurrence.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t RT = 4096;
+__global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ R) {
+    __shared__ __attribute__((aligned(16))) uint8_t s[RT + 258 + 16];  // s[i] = in[E - 1 + i]
+    const uint32_t tid = threadIdx.x;
+    const uint64_t E = (uint64_t)blockIdx.x * RT;
+    for (uint32_t i = tid; i < RT + 258 + 16; i += 256) {
+        int64_t g = (int64_t)E - 1 + i;
+        s[i] = (g >= 0 && (uint64_t)g < n) ? in[g] : 0;
+    }
+    __syncthreads();
+    // eq(i) <=> in[E+i] == in[E+i-1], valid for E+i in [1, n)
+    auto eq = [&](uint32_t i) -> bool {
+        uint64_t g = E + i;
+        return g >= 1 && g < n && s[i + 1] == s[i];
+    };
+    uint32_t q = tid * 16 + 16;  // first position after my chunk (tile relative)
+    uint32_t c = 0;
+    while (c < MAX_MATCH && q + c < RT + 258 + 14 && eq(q + c)) c++;
+    for (int i = 15; i >= 0; i--) {
+        uint32_t pr = tid * 16 + i;
+        uint64_t g = E + pr;
+        c = eq(pr) ? c + 1 : 0;
+        if (c > 65535) c = 65535;
+        if (g < n) R[g] = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_adv: lz77.rs:305-547 / rle.rs:23-71 seen from a restart position: how far does the parser
+// get before it is again in a state that depends on the position only.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
+                                             ParseCfg cfg, uint16_t* __restrict__ adv) {
+    uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    GM m{M}, mq{Mq ? Mq : M};
+    adv[j] = (uint16_t)parse_step(m, mq, j, (uint64_t)n, cfg).adv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_seg_exit: for every position of a segment the first path position at or beyond the end of
+// the segment (right-to-left sweep), and the level-0 table over the segment's entry zone.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
+                                                 uint16_t* __restrict__ J, uint32_t* __restrict__ X0) {
+    uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    for (uint64_t j = b; j-- > a;) {
+        uint64_t t = j + adv[j];
+        J[j] = (uint16_t)(t >= b ? t - b : J[t]);
+    }
+    uint32_t* x = X0 + k * ZONE;
+    for (uint32_t e = 0; e < ZONE; e++) x[e] = (a + e < b) ? (uint32_t)J[a + e] : (uint32_t)(a + e - b);
+}
+
+// k_level_up: compose FAN child tables into one parent table.
+__global__ __launch_bounds__(256) void k_level_up(uint32_t n, uint32_t nc, uint64_t csize,
+                                                  const uint32_t* __restrict__ C, uint32_t nu,
+                                                  uint32_t* __restrict__ X) {
+    uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (uint64_t)nu * ZONE) return;
+    uint64_t u = gid / ZONE;
+    uint32_t e = (uint32_t)(gid % ZONE);
+    uint64_t usize = csize * FAN;
+    uint64_t ustart = u * usize;
+    uint64_t uend = ustart + usize < n ? ustart + usize : n;
+    uint64_t pos = ustart + e;
+    uint64_t c1 = (u + 1) * FAN < nc ? (u + 1) * FAN : nc;
+    for (uint64_t c = u * FAN; c < c1; c++) {
+        uint64_t cstart = c * csize;
+        uint64_t cend = cstart + csize < n ? cstart + csize : n;
+        if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
+    }
+    X[gid] = (uint32_t)(pos - uend);
+}
+
+// k_level_down: given the entry position of every parent unit, the entry of each child.
+__global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint64_t csize,
+                                                   const uint32_t* __restrict__ C, uint32_t nu,
+                                                   const uint32_t* __restrict__ Eparent, uint32_t* __restrict__ Echild) {
+    uint64_t u = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (u >= nu) return;
+    uint64_t pos = Eparent ? Eparent[u] : 0;
+    uint64_t c1 = (u + 1) * FAN < nc ? (u + 1) * FAN : nc;
+    for (uint64_t c = u * FAN; c < c1; c++) {
+        uint64_t cstart = c * csize;
+        uint64_t cend = cstart + csize < n ? cstart + csize : n;
+        Echild[c] = (uint32_t)pos;
+        if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_emit: walk each segment from its entry and write its tokens (output_writer.rs:47-65).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
+                                             const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
+                                             ParseCfg cfg, const uint32_t* __restrict__ E0,
+                                             uint32_t* __restrict__ tokbuf, uint32_t* __restrict__ cnt) {
+    uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    GM m{M}, mq{Mq ? Mq : M};
+    uint32_t* out = tokbuf + a;
+    uint32_t i = 0;
+    uint64_t j = E0[k];
+    while (j < b) {
+        Step st = parse_step(m, mq, j, (uint64_t)n, cfg);
+        for (uint32_t q = 0; q < st.nlit; q++) out[i++] = tok_literal(in[j + q]);
+        if (st.mlen) out[i++] = tok_match(st.mlen, st.mdist);
+        j += st.adv;
+    }
+    cnt[k] = i;
+}
+
+// k_scan: exclusive scan of the per-segment token counts (single workgroup).
+__global__ __launch_bounds__(1024) void k_scan(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base,
+                                               DevScalars* sc) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    uint64_t per = ((uint64_t)K + 1023) / 1024;
+    uint64_t lo = tid * per, hi = lo + per < K ? lo + per : K;
+    uint32_t s = 0;
+    for (uint64_t i = lo; i < hi; i++) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint64_t i = lo; i < hi; i++) {
+        base[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) {
+        uint32_t T = part[1023];
+        sc->T = T;
+        sc->nb = T / MAX_BUFFER_LENGTH + 1;
+    }
+}
+
+// k_compact: tokens of all segments into one dense stream.
+__global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __restrict__ tokbuf,
+                                                 const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
+                                                 uint32_t* __restrict__ dtok) {
+    uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t c = cnt[k], b = base[k];
+    const uint32_t* src = tokbuf + k * SEG;
+    for (uint32_t i = lane; i < c; i += 64) dtok[b + i] = src[i];
+}
+
+// start position of token t (t < T)
+__device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, const uint32_t* E0,
+                                const uint32_t* tokbuf) {
+    uint32_t lo = 0, hi = K;  // last k with base[k] <= t
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (base[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    uint32_t pos = E0[lo];
+    const uint32_t* tk = tokbuf + (uint64_t)lo * SEG;
+    for (uint32_t i = 0, m = t - base[lo]; i < m; i++) pos += tok_cover(tk[i]);
+    return pos;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_block_bounds: where each 31744-token block (output_writer.rs:19,38-44) starts in the input,
+// the data for the Q1 decision, and the Q13 condition per block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode,
+                                                     const uint32_t* __restrict__ base, const uint32_t* __restrict__ E0,
+                                                     const uint32_t* __restrict__ tokbuf,
+                                                     const uint32_t* __restrict__ dtok, DevScalars* sc,
+                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13) {
+    uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b > nb_max) return;
+    uint32_t T = sc->T, nb = sc->nb;
+    if (b > nb) return;
+    if (b == nb) {
+        bstart[b] = n;
+        return;
+    }
+    uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
+    bstart[b] = t0 < T ? token_start((uint32_t)t0, K, base, E0, tokbuf) : n;
+    uint32_t flag = 0;
+    if (t0 + MAX_BUFFER_LENGTH <= T) {  // a full block: look at its last token
+        uint32_t t1 = (uint32_t)(t0 + MAX_BUFFER_LENGTH - 1);
+        uint32_t tk = dtok[t1];
+        uint32_t tp = token_start(t1, K, base, E0, tokbuf);
+        if (b == 0) {
+            sc->b0_full = 1;
+            sc->b0_last_tok = tk;
+            sc->b0_last_pos = tp;
+        }
+        if (tk >> 16) {  // lz77.rs:679-695
+            uint64_t lp = (mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
+            uint64_t wdx = lp / WINDOW_SIZE;
+            uint64_t wend = (wdx + 1) * (uint64_t)WINDOW_SIZE;
+            uint64_t mend = (uint64_t)tp + tok_cover(tk);
+            if (wdx >= 1 && mend > wend) {
+                uint64_t buf_end = wdx * (uint64_t)WINDOW_SIZE + 65794;
+                if (buf_end > n) buf_end = n;
+                flag = (mend + WINDOW_SIZE > buf_end) ? 2u : 1u;
+            }
+        }
+    }
+    q13[b] = flag;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_block_hist: output_writer.rs:47-65,75-85 -- literal/length and distance frequencies of one
+// block, reduced in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
+                                                    uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq) {
+    __shared__ uint32_t h[320];
+    uint32_t b = blockIdx.x;
+    if (b >= sc->nb) return;
+    for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
+    __syncthreads();
+    uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
+    uint64_t t1 = t0 + MAX_BUFFER_LENGTH < sc->T ? t0 + MAX_BUFFER_LENGTH : sc->T;
+    for (uint64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+        uint32_t tk = dtok[t];
+        if (tk >> 16) {
+            uint32_t c, eb, ev;
+            length_symbol(tk & 0xff, &c, &eb, &ev);
+            atomicAdd(&h[257 + c], 1u);
+            distance_symbol(tk >> 16, &c, &eb, &ev);
+            atomicAdd(&h[288 + c], 1u);
+        } else {
+            atomicAdd(&h[tk & 0xff], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) h[END_OF_BLOCK] += 1;  // output_writer.rs:83
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 288; i += 256) ll_freq[(uint64_t)b * 288 + i] = i < NUM_LL ? h[i] : 0;
+    for (uint32_t i = threadIdx.x; i < 32; i += 256) d_freq[(uint64_t)b * 32 + i] = i < NUM_DIST ? h[288 + i] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_block_header: huffman_lengths.rs:167-266 for one block per wave: three length-limited
+// Huffman codes (length_encode.rs:347-415), the run-length coded table (length_encode.rs:82-155)
+// and the cost figures.  The sort is a 64-lane rank sort on (freq << 9 | symbol), which equals
+// the reference's stable sort by freq; the Moffat-Katajainen passes and the limiter run in
+// lane 0 on LDS arrays.
+// ---------------------------------------------------------------------------------------------
+struct HdrLds {
+    uint32_t llf[288];
+    uint32_t df[32];
+    uint32_t clf[19];
+    uint32_t m;
+    HuffNode nodes[288];
+    HuffNode sorted[288];
+    uint8_t ll_len[288];
+    uint8_t d_len[32];
+    uint8_t cl_len[20];
+    uint8_t chain[320];
+    uint16_t enc[320];
+    uint32_t n_ll, n_d, n_enc, used;
+};
+
+template <class LenArr>
+__device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
+                          LenArr& lengths, uint32_t lane) {
+    for (uint32_t i = lane; i < n_total; i += 64) lengths[i] = 0;
+    __syncthreads();
+    if (lane == 0) s.m = gather_nodes(freqs, n, s.nodes);
+    __syncthreads();
+    uint32_t m = s.m;
+    if (m >= 2) {
+        for (uint32_t i = lane; i < m; i += 64) {
+            uint32_t key = (s.nodes[i].value << 9) | s.nodes[i].symbol;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; j++) rank += ((s.nodes[j].value << 9) | s.nodes[j].symbol) < key ? 1u : 0u;
+            s.sorted[rank] = s.nodes[i];
+        }
+    } else if (lane == 0 && m == 1) {
+        s.sorted[0] = s.nodes[0];
+    }
+    __syncthreads();
+    if (lane == 0) lengths_from_sorted(s.sorted, m, max_len, lengths);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
+                                                     const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr) {
+    __shared__ HdrLds s;
+    uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b >= sc->nb) return;
+    for (uint32_t i = lane; i < 288; i += 64) s.llf[i] = ll_freq[(uint64_t)b * 288 + i];
+    if (lane < 32) s.df[lane] = d_freq[(uint64_t)b * 32 + lane];
+    if (lane < 19) s.clf[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        s.n_ll = trimmed_count(s.llf, NUM_LL, 257);
+        s.n_d = trimmed_count(s.df, NUM_DIST, 1);
+    }
+    __syncthreads();
+    wave_huff(s, s.llf, s.n_ll, 288, 15, s.ll_len, lane);
+    wave_huff(s, s.df, s.n_d, 32, 15, s.d_len, lane);
+    for (uint32_t i = lane; i < s.n_ll; i += 64) s.chain[i] = s.ll_len[i];
+    for (uint32_t i = lane; i < s.n_d; i += 64) s.chain[s.n_ll + i] = s.d_len[i];
+    __syncthreads();
+    if (lane == 0) s.n_enc = encode_lengths_rle(s.chain, s.n_ll + s.n_d, s.enc, s.clf);
+    __syncthreads();
+    wave_huff(s, s.clf, 19, 19, 7, s.cl_len, lane);
+    BlockHeader* h = hdr + b;
+    if (lane == 0) {
+        s.used = count_used_hclens(s.cl_len);
+        uint64_t dyn_bits, dyn_est, static_est, fixed_bits;
+        const uint32_t* pl = s.llf;
+        const uint32_t* pd = s.df;
+        block_costs(pl, pd, s.clf, s.ll_len, s.d_len, s.cl_len, s.n_ll, s.n_d, s.used, &dyn_bits, &dyn_est, &static_est,
+                    &fixed_bits);
+        h->n_enc = s.n_enc;
+        h->n_ll = s.n_ll;
+        h->n_d = s.n_d;
+        h->used_hclens = s.used;
+        h->dyn_bits = dyn_bits;
+        h->dyn_est = dyn_est;
+        h->static_est = static_est;
+        h->fixed_bits = fixed_bits;
+    }
+    for (uint32_t i = lane; i < 288; i += 64) h->ll_len[i] = s.ll_len[i];
+    if (lane < 32) h->d_len[lane] = s.d_len[lane];
+    if (lane < 19) h->cl_len[lane] = s.cl_len[lane];
+    __syncthreads();
+    for (uint32_t i = lane; i < s.n_enc; i += 64) h->enc[i] = s.enc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_plan: compress.rs:157-246 -- the one strictly serial step: block type (needs the bit phase,
+// huffman_lengths.rs:269), bit offsets, BFINAL.  One wave; each lane loads one block, the wave
+// then steps through its 64 blocks in order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
+                                             const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
+                                             BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nb = sc->nb;
+    uint64_t bitpos = bit_base;
+    uint32_t n_st = 0, n_fx = 0, n_dy = 0, hits = 0, panic = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+        uint32_t b = b0 + lane;
+        bool have = b < nb;
+        uint64_t dyn_bits = 0, dyn_est = 0, static_est = 0, fixed_bits = 0, in_bytes = 0;
+        if (have) {
+            dyn_bits = hdr[b].dyn_bits;
+            dyn_est = hdr[b].dyn_est;
+            static_est = hdr[b].static_est;
+            fixed_bits = hdr[b].fixed_bits;
+            in_bytes = (uint64_t)bstart[b + 1] - bstart[b];
+        }
+        // f(phase) for the 8 possible phases is tiny, but a plain in-order walk is enough here
+        uint32_t cnt = nb - b0 < 64 ? nb - b0 : 64;
+        for (uint32_t sidx = 0; sidx < cnt; sidx++) {
+            uint64_t len = 0;
+            if (lane == sidx) {
+                BlockPlan p;
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb, bitpos, &p);
+                plan[b] = p;
+                len = p.bit_len;
+                if (p.btype == BT_STORED) {
+                    n_st++;
+                    if (q13[b]) {
+                        hits++;
+                        if (q13[b] == 2 && (compat & 1)) panic = 1;
+                    }
+                } else if (p.btype == BT_FIXED) {
+                    n_fx++;
+                } else {
+                    n_dy++;
+                }
+            }
+            uint32_t len_lo = __shfl((uint32_t)len, sidx), len_hi = __shfl((uint32_t)(len >> 32), sidx);
+            bitpos += ((uint64_t)len_hi << 32) | len_lo;
+        }
+    }
+    // reduce the per-lane counters
+    for (int off = 32; off; off >>= 1) {
+        n_st += __shfl_down(n_st, off);
+        n_fx += __shfl_down(n_fx, off);
+        n_dy += __shfl_down(n_dy, off);
+        hits += __shfl_down(hits, off);
+        panic |= __shfl_down(panic, off);
+    }
+    if (lane == 0) {
+        sc->total_bits = bitpos - bit_base;
+        sc->n_stored = n_st;
+        sc->n_fixed = n_fx;
+        sc->n_dynamic = n_dy;
+        sc->q13_hits = hits;
+        sc->ref_panic = panic;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack: encoder_state.rs:58-105 + bitstream.rs:76-86 + stored_block.rs:13-40 for one block per
+// workgroup.  Tokens are coded 256 at a time: per-lane bit string, workgroup exclusive scan of
+// the lengths, then OR into the zeroed output words (seams between lanes and blocks share
+// words, hence atomicOr).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint64_t bits, uint32_t nbits) {
+    if (nbits == 0) return;
+    uint64_t w = bitpos >> 5;
+    uint32_t sh = (uint32_t)(bitpos & 31);
+    uint64_t lo = bits << sh;                    // bits 0..63 of the shifted value
+    uint32_t hi = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+    uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+    if (w0) atomicOr(out32 + w, w0);
+    if (w1) atomicOr(out32 + w + 1, w1);
+    if (hi) atomicOr(out32 + w + 2, hi);
+}
+
+struct PackLds {
+    uint16_t llc[288];
+    uint16_t dc[32];
+    uint16_t clc[20];
+    uint8_t lll[288];
+    uint8_t dl[32];
+    uint32_t scan[256];
+    uint32_t carry;
+};
+
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, uint32_t n,
+                                              const uint32_t* __restrict__ dtok, const DevScalars* sc,
+                                              const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
+                                              const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
+                                              uint32_t compat, uint32_t* __restrict__ out32) {
+    __shared__ PackLds s;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (b >= sc->nb) return;
+    const BlockPlan pl = plan[b];
+    const BlockHeader* h = hdr + b;
+    uint64_t bp = pl.bit_start;
+    if (pl.btype == BT_STORED) {
+        // compress.rs:59-77, stored_block.rs:13-40
+        uint64_t src = bstart[b];
+        if (q13[b] && (compat & 1)) src += WINDOW_SIZE;  // bug-for-bug (A.4 Q13)
+        uint64_t left = (uint64_t)bstart[b + 1] - bstart[b];
+        do {
+            uint64_t piece = left < (uint64_t)MAX_STORED_BLOCK_LENGTH ? left : (uint64_t)MAX_STORED_BLOCK_LENGTH;
+            bool last_piece = piece == left;
+            uint64_t hb = (bp + 3 + 7) & ~7ull;  // header bits then pad to a byte
+            if (tid == 0) {
+                put_bits(out32, bp, (pl.bfinal && last_piece) ? 1u : 0u, 3);
+                put_bits(out32, hb, (piece & 0xffff) | (((~piece) & 0xffff) << 16), 32);
+            }
+            uint64_t ob = (hb >> 3) + 4;  // first payload byte
+            // whole output words in the middle are plain stores; ragged ends go byte-wise via OR
+            for (uint64_t i = tid; i < piece; i += 256) {
+                uint64_t o = ob + i;
+                uint32_t v = (src + i < n) ? in[src + i] : 0u;
+                if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
+            }
+            bp = (ob + piece) * 8;
+            src += piece;
+            left -= piece;
+        } while (left > 0);
+        return;
+    }
+    // code tables
+    if (pl.btype == BT_FIXED) {
+        for (uint32_t i = tid; i < 288; i += 256) s.lll[i] = (uint8_t)fixed_ll_length(i);
+        if (tid < 32) s.dl[tid] = 5;
+    } else {
+        for (uint32_t i = tid; i < 288; i += 256) s.lll[i] = h->ll_len[i];
+        if (tid < 32) s.dl[tid] = h->d_len[tid];
+    }
+    for (uint32_t i = tid; i < 288; i += 256) s.llc[i] = 0;
+    if (tid < 32) s.dc[tid] = 0;
+    if (tid < 20) s.clc[tid] = 0;
+    __syncthreads();
+    if (tid == 0) canonical_codes(s.lll, 288, s.llc);  // huffman_table.rs:253-278
+    if (tid == 64) canonical_codes(s.dl, 32, s.dc);
+    if (tid == 128 && pl.btype == BT_DYNAMIC) canonical_codes(h->cl_len, 19, s.clc);
+    __syncthreads();
+    // block header
+    uint32_t hdr_bits = 3;
+    if (pl.btype == BT_DYNAMIC) {
+        // the header length follows from the plan: dyn_bits = header + body
+        if (tid == 0) {
+            uint64_t p = bp;
+            put_bits(out32, p, pl.bfinal ? 5u : 4u, 3);  // encoder_state.rs:12-13
+            p += 3;
+            put_bits(out32, p, (h->n_ll - 257) | ((h->n_d - 1) << 5) | ((h->used_hclens >= 4 ? h->used_hclens - 4 : 0) << 10), 14);
+            p += 14;
+            for (uint32_t i = 0; i < h->used_hclens; i++) {  // huffman_lengths.rs:329-331
+                put_bits(out32, p, h->cl_len[hclen_order(i)], 3);
+                p += 3;
+            }
+            for (uint32_t i = 0; i < h->n_enc; i++) {  // :338-368
+                uint32_t e = h->enc[i], kind = e >> 8, v = e & 0xff;
+                uint32_t sym = el_symbol_index(e);
+                uint32_t cl = h->cl_len[sym];
+                uint64_t bits = s.clc[sym];
+                uint32_t nb2 = cl;
+                if (kind == 1) {
+                    bits |= (uint64_t)(v - 3) << nb2;
+                    nb2 += 2;
+                } else if (kind == 2) {
+                    bits |= (uint64_t)(v - 3) << nb2;
+                    nb2 += 3;
+                } else if (kind == 3) {
+                    bits |= (uint64_t)(v - 11) << nb2;
+                    nb2 += 7;
+                }
+                put_bits(out32, p, bits, nb2);
+                p += nb2;
+            }
+            s.carry = (uint32_t)(p - bp);
+        }
+        __syncthreads();
+        hdr_bits = s.carry;
+        __syncthreads();
+    } else if (tid == 0) {
+        put_bits(out32, bp, pl.bfinal ? 3u : 2u, 3);  // encoder_state.rs:10-11
+    }
+    bp += hdr_bits;
+    // tokens
+    const uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
+    const uint64_t t1 = t0 + MAX_BUFFER_LENGTH < sc->T ? t0 + MAX_BUFFER_LENGTH : sc->T;
+    for (uint64_t tb = t0; tb < t1; tb += 256) {
+        uint64_t t = tb + tid;
+        uint32_t nbits = 0;
+        uint64_t bits = 0;
+        if (t < t1) bits = token_bits(dtok[t], s.llc, s.lll, s.dc, s.dl, &nbits);
+        s.scan[tid] = nbits;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            uint32_t v = tid >= off ? s.scan[tid - off] : 0;
+            __syncthreads();
+            s.scan[tid] += v;
+            __syncthreads();
+        }
+        uint32_t incl = s.scan[tid];
+        uint32_t total = s.scan[255];
+        put_bits(out32, bp + (incl - nbits), bits, nbits);
+        bp += total;
+        __syncthreads();
+    }
+    if (tid == 0) put_bits(out32, bp, s.llc[END_OF_BLOCK], s.lll[END_OF_BLOCK]);  // encoder_state.rs:102-105
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adler-32 (RFC 1950; crate adler32 as used by checksum.rs:33-57): per-chunk (a, b) partials,
+// then one lane folds them: a' = a + a_c, b' = b + len_c * a + b_c (mod 65521).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t ADLER_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_adler_part(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ pa,
+                                                    uint32_t* __restrict__ pb) {
+    __shared__ uint32_t sa[256], sb[256];
+    uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
+    uint32_t len = n - c0 < ADLER_CHUNK ? (uint32_t)(n - c0) : ADLER_CHUNK;
+    uint32_t a = 0, b = 0;
+    // b part of byte i (0-based in the chunk) is (len - i) * d
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        uint32_t d = in[c0 + i];
+        a += d;
+        b += (len - i) * d;  // <= 16 * 4096 * 255 < 2^32
+    }
+    sa[threadIdx.x] = a;
+    sb[threadIdx.x] = b % 65521u;
+    __syncthreads();
+    for (uint32_t off = 128; off; off >>= 1) {
+        if (threadIdx.x < off) {
+            sa[threadIdx.x] += sa[threadIdx.x + off];
+            sb[threadIdx.x] = (sb[threadIdx.x] + sb[threadIdx.x + off]) % 65521u;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pa[blockIdx.x] = sa[0] % 65521u;
+        pb[blockIdx.x] = sb[0];
+    }
+}
+__global__ void k_adler_fold(uint32_t n, uint32_t nchunks, const uint32_t* __restrict__ pa,
+                             const uint32_t* __restrict__ pb, DevScalars* sc) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t a = 1, b = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        uint64_t c0 = (uint64_t)c * ADLER_CHUNK;
+        uint64_t len = n - c0 < ADLER_CHUNK ? n - c0 : ADLER_CHUNK;
+        b = (b + len * a + pb[c]) % 65521u;
+        a = (a + pa[c]) % 65521u;
+    }
+    sc->adler = (uint32_t)((b << 16) | a);
+}
+
+// zlib framing written on the device (lib.rs:182-198, zlib.rs:59-62): 78 9C, Adler-32 BE.
+__global__ void k_zlib_frame(DevScalars* sc, uint8_t* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t nbytes = (sc->total_bits + 7) / 8;
+    out[0] = 0x78;
+    out[1] = 0x9C;
+    uint32_t a = sc->adler;
+    out[2 + nbytes + 0] = (uint8_t)(a >> 24);
+    out[2 + nbytes + 1] = (uint8_t)(a >> 16);
+    out[2 + nbytes + 2] = (uint8_t)(a >> 8);
+    out[2 + nbytes + 3] = (uint8_t)a;
+}
+
+}  // namespace mi355
+
+#include "deflate_host.inc"

@@ -514,80 +514,105 @@ MI355_HD void sort_nodes(NodeArr& a, uint32_t n) {
     }
 }
 
-// in_place_lengths length_encode.rs:347-415 for one alphabet: freqs[0..n) -> lengths[0..n_total)
-// (all n_total entries are zeroed first, :355-357).  `scratch` needs n entries.
+// in_place_lengths length_encode.rs:347-415, split into the pieces the block-header kernel
+// runs: gather the used symbols, sort them by (freq, symbol), then lengths_from_sorted.
+template <class FreqArr, class NodeArr>
+MI355_HD uint32_t gather_nodes(const FreqArr& freqs, uint32_t n, NodeArr& nodes) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (freqs[i] > 0) {
+            nodes[m].value = freqs[i];
+            nodes[m].symbol = i;
+            m++;
+        }
+    return m;
+}
+// lengths[] already zeroed for the whole output slice (:355-357); special cases :377-382
+template <class NodeArr, class LenArr>
+MI355_HD void lengths_from_sorted(NodeArr& nodes, uint32_t m, uint32_t max_len, LenArr& lengths) {
+    if (m == 0) return;
+    if (m == 1) {
+        lengths[nodes[0].symbol] = 1;
+        return;
+    }
+    huff_lengths_sorted(nodes, m, max_len, lengths);
+}
 template <class FreqArr, class LenArr, class NodeArr>
 MI355_HD void huff_lengths(const FreqArr& freqs, uint32_t n, uint32_t n_total, uint32_t max_len, LenArr& lengths,
                            NodeArr& scratch) {
     for (uint32_t i = 0; i < n_total; i++) lengths[i] = 0;
-    uint32_t m = 0;
-    for (uint32_t i = 0; i < n; i++)
-        if (freqs[i] > 0) {
-            scratch[m].value = freqs[i];
-            scratch[m].symbol = i;
-            m++;
-        }
-    if (m == 0) return;
-    if (m == 1) {
-        lengths[scratch[0].symbol] = 1;
-        return;
-    }
-    sort_nodes(scratch, m);
-    huff_lengths_sorted(scratch, m, max_len, lengths);
+    uint32_t m = gather_nodes(freqs, n, scratch);
+    if (m >= 2) sort_nodes(scratch, m);
+    lengths_from_sorted(scratch, m, max_len, lengths);
 }
 
-// gen_huffman_lengths huffman_lengths.rs:167-287 minus the block-type choice (which needs the
-// bit phase and is made by plan_block).  ll_freq[286] (EOB already counted), d_freq[30].
-template <class FreqArr, class NodeArr>
-MI355_HD void build_block_header(const FreqArr& ll_freq, const FreqArr& d_freq, BlockHeader& h, NodeArr& scratch) {
-    // remove_trailing_zeroes :44-47
-    uint32_t n_ll = NUM_LL;
-    while (n_ll > 257 && ll_freq[n_ll - 1] == 0) n_ll--;
-    uint32_t n_d = NUM_DIST;
-    while (n_d > 1 && d_freq[n_d - 1] == 0) n_d--;
-    huff_lengths(ll_freq, n_ll, 288, 15, h.ll_len, scratch);
-    huff_lengths(d_freq, n_d, 32, 15, h.d_len, scratch);
-    h.n_ll = n_ll;
-    h.n_d = n_d;
-    // chained lengths :212-218
-    uint8_t chain[320];
-    for (uint32_t i = 0; i < n_ll; i++) chain[i] = h.ll_len[i];
-    for (uint32_t i = 0; i < n_d; i++) chain[n_ll + i] = h.d_len[i];
-    uint32_t cl_freq[19];
-    for (int i = 0; i < 19; i++) cl_freq[i] = 0;
-    h.n_enc = encode_lengths_rle(chain, n_ll + n_d, h.enc, cl_freq);
-    huff_lengths(cl_freq, 19, 19, 7, h.cl_len, scratch);
-    uint32_t used = 19;  // :230-235
-    while (used > 0 && h.cl_len[hclen_order(used - 1)] == 0) used--;
-    h.used_hclens = used;
-    // costs :241-266
-    uint64_t d_ll = 0, s_ll = 0, f_ll = 0;
+// remove_trailing_zeroes huffman_lengths.rs:44-47
+template <class FreqArr>
+MI355_HD uint32_t trimmed_count(const FreqArr& f, uint32_t n, uint32_t min_len) {
+    while (n > min_len && f[n - 1] == 0) n--;
+    return n;
+}
+// used_hclens huffman_lengths.rs:230-235
+template <class LenArr>
+MI355_HD uint32_t count_used_hclens(const LenArr& cl_len) {
+    uint32_t used = 19;
+    while (used > 0 && cl_len[hclen_order(used - 1)] == 0) used--;
+    return used;
+}
+// The bit costs of huffman_lengths.rs:241-266 plus the real sizes (see BlockHeader).
+template <class FreqArr, class CFreqArr, class LLLen, class DLen, class CLLen>
+MI355_HD void block_costs(const FreqArr& ll_freq, const FreqArr& d_freq, const CFreqArr& cl_freq, const LLLen& ll_len,
+                          const DLen& d_len, const CLLen& cl_len, uint32_t n_ll, uint32_t n_d, uint32_t used,
+                          uint64_t* dyn_bits, uint64_t* dyn_est, uint64_t* static_est, uint64_t* fixed_bits) {
+    uint64_t d_ll = 0, s_ll = 0;
     for (uint32_t c = 0; c < n_ll; c++) {
         uint64_t f = ll_freq[c];
         uint64_t extra = c >= 257 ? length_extra_bits_of_code(c - 257) : 0;
-        d_ll += f * (h.ll_len[c] + extra);
+        d_ll += f * (ll_len[c] + extra);
         s_ll += f * (fixed_ll_length(c) + extra);
     }
-    f_ll = s_ll;
     uint64_t d_d = 0, s_d = 0, f_d = 0;
     for (uint32_t c = 0; c < n_d; c++) {
         uint64_t f = d_freq[c];
         uint64_t extra = distance_extra_bits_of_code(c);
-        d_d += f * (h.d_len[c] + extra);
+        d_d += f * (d_len[c] + extra);
         s_d += f * (fixed_ll_length(c) + extra);  // Q12: the ll table is used for distances too
         f_d += f * (5 + extra);
     }
     uint64_t table = 0, table_real = 0;  // calculate_huffman_length :59-68
     for (uint32_t i = 0; i < 19; i++) {
         uint64_t extra = (i == 16 || i == 17) ? 3 : (i == 18 ? 7 : 0);
-        uint64_t extra_real = i == 16 ? 2 : extra;  // write_huffman_lengths :343
-        table += (uint64_t)cl_freq[i] * (h.cl_len[i] + extra);
-        table_real += (uint64_t)cl_freq[i] * (h.cl_len[i] + extra_real);
+        uint64_t extra_real = i == 16 ? 2 : extra;  // write_huffman_lengths :343 writes 2 bits
+        table += (uint64_t)cl_freq[i] * (cl_len[i] + extra);
+        table_real += (uint64_t)cl_freq[i] * (cl_len[i] + extra_real);
     }
-    h.dyn_est = d_ll + d_d + table + (uint64_t)used * 3 + 5 + 5 + 4;
-    h.dyn_bits = d_ll + d_d + table_real + (uint64_t)used * 3 + 5 + 5 + 4;
-    h.static_est = s_ll + s_d;
-    h.fixed_bits = f_ll + f_d;
+    *dyn_est = d_ll + d_d + table + (uint64_t)used * 3 + 5 + 5 + 4;
+    *dyn_bits = d_ll + d_d + table_real + (uint64_t)used * 3 + 5 + 5 + 4;
+    *static_est = s_ll + s_d;
+    *fixed_bits = s_ll + f_d;
+}
+
+// gen_huffman_lengths huffman_lengths.rs:167-287 minus the block-type choice (which needs the
+// bit phase and is made by plan_block).  ll_freq[286] (EOB already counted), d_freq[30].
+// Host composite of the pieces above; the kernel k_block_header runs the same pieces.
+template <class FreqArr, class NodeArr>
+MI355_HD void build_block_header(const FreqArr& ll_freq, const FreqArr& d_freq, BlockHeader& h, NodeArr& scratch) {
+    uint32_t n_ll = trimmed_count(ll_freq, NUM_LL, 257);
+    uint32_t n_d = trimmed_count(d_freq, NUM_DIST, 1);
+    huff_lengths(ll_freq, n_ll, 288, 15, h.ll_len, scratch);
+    huff_lengths(d_freq, n_d, 32, 15, h.d_len, scratch);
+    h.n_ll = n_ll;
+    h.n_d = n_d;
+    uint8_t chain[320];  // chained lengths :212-218
+    for (uint32_t i = 0; i < n_ll; i++) chain[i] = h.ll_len[i];
+    for (uint32_t i = 0; i < n_d; i++) chain[n_ll + i] = h.d_len[i];
+    uint32_t cl_freq[19];
+    for (int i = 0; i < 19; i++) cl_freq[i] = 0;
+    h.n_enc = encode_lengths_rle(chain, n_ll + n_d, h.enc, cl_freq);
+    huff_lengths(cl_freq, 19, 19, 7, h.cl_len, scratch);
+    h.used_hclens = count_used_hclens(h.cl_len);
+    block_costs(ll_freq, d_freq, cl_freq, h.ll_len, h.d_len, h.cl_len, n_ll, n_d, h.used_hclens, &h.dyn_bits,
+                &h.dyn_est, &h.static_est, &h.fixed_bits);
 }
 
 // ---- block plan (compress.rs:157-246, huffman_lengths.rs:179,269-286) ---------------------
@@ -615,16 +640,18 @@ MI355_HD uint64_t stored_total_bits(uint64_t nbytes, uint32_t phase) {
     return bits;
 }
 
-// Decide one block.  in_bytes = bytes its tokens cover, ntok unused except for clarity.
-MI355_HD void plan_block(const BlockHeader& h, uint64_t in_bytes, bool is_last, uint64_t bit_pos, BlockPlan* out) {
+// Decide one block from its four cost figures (BlockHeader), the bytes its tokens cover and the
+// bit position it starts at.
+MI355_HD void plan_block(uint64_t dyn_bits, uint64_t dyn_est, uint64_t static_est, uint64_t fixed_bits,
+                         uint64_t in_bytes, bool is_last, uint64_t bit_pos, BlockPlan* out) {
     uint32_t btype;
     if (in_bytes <= 4) {  // huffman_lengths.rs:179-181
         btype = BT_FIXED;
     } else {
         uint64_t stored = stored_length_bits(in_bytes) + stored_padding((uint32_t)(bit_pos & 7));  // :269
-        uint64_t used = h.dyn_est < h.static_est ? h.dyn_est : h.static_est;
+        uint64_t used = dyn_est < static_est ? dyn_est : static_est;
         if (stored < used) used = stored;
-        if (used == h.static_est)
+        if (used == static_est)
             btype = BT_FIXED;  // :277-286 (Q5)
         else if (used == stored)
             btype = BT_STORED;
@@ -635,9 +662,9 @@ MI355_HD void plan_block(const BlockHeader& h, uint64_t in_bytes, bool is_last, 
     out->bfinal = is_last ? 1 : 0;
     out->bit_start = bit_pos;
     if (btype == BT_FIXED)
-        out->bit_len = 3 + h.fixed_bits;
+        out->bit_len = 3 + fixed_bits;
     else if (btype == BT_DYNAMIC)
-        out->bit_len = 3 + h.dyn_bits;
+        out->bit_len = 3 + dyn_bits;
     else
         out->bit_len = stored_total_bits(in_bytes, (uint32_t)(bit_pos & 7));
 }

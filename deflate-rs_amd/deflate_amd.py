@@ -1,0 +1,325 @@
+"""Python host side of the MI355X DEFLATE encode path: a ctypes binding of libmi355deflate.so
+(include/mi355_deflate.h) shaped like the reference's public API so that tests read like the
+reference's own (src/lib.rs:137-216, src/writer.rs:89-290, src/compression_options.rs).
+
+There is no CPU fallback here.  Importing works anywhere (so the symbol check can run on a
+machine without a GPU); every encode call goes through the HIP kernels and raises if the library
+or a gfx950 device is missing.
+"""
+import ctypes as C
+import enum
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355deflate.so")
+
+OK, E_ARG, E_OUT_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_REF_PANIC, E_STATE = 0, -1, -2, -3, -4, -5, -6
+COMPAT_Q13 = 1
+
+STAGES = ["links", "match", "parse", "blocks", "pack", "other"]
+
+
+class Opts(C.Structure):
+    _fields_ = [("max_hash_checks", C.c_uint16), ("lazy_if_less_than", C.c_uint16),
+                ("matching_type", C.c_uint8), ("wrapper", C.c_uint8), ("compat", C.c_uint8),
+                ("reserved", C.c_uint8)]
+
+
+class Info(C.Structure):
+    _fields_ = [("in_len", C.c_uint64), ("out_len", C.c_uint64), ("n_tokens", C.c_uint64),
+                ("n_blocks", C.c_uint32), ("n_stored", C.c_uint32), ("n_fixed", C.c_uint32),
+                ("n_dynamic", C.c_uint32), ("q1_rewarm", C.c_uint32), ("q13_hits", C.c_uint32),
+                ("passes", C.c_uint32), ("reserved", C.c_uint32), ("stage_ms", C.c_float * 6),
+                ("total_ms", C.c_float), ("match_launches", C.c_uint32), ("match_ms", C.c_float)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("btype", C.c_uint32), ("bfinal", C.c_uint32), ("n_tokens", C.c_uint32), ("reserved", C.c_uint32),
+                ("in_bytes", C.c_uint64), ("bit_start", C.c_uint64)]
+
+
+class MatchingType(enum.IntEnum):
+    """src/lz77.rs:27-37"""
+    Greedy = 0
+    Lazy = 1
+
+
+class Compression(enum.IntEnum):
+    """src/compression_options.rs:31-42"""
+    Fast = 0
+    Default = 1
+    Best = 2
+
+
+class CompressionOptions:
+    """src/compression_options.rs:78-120; profiles :126-178."""
+
+    def __init__(self, max_hash_checks=128, lazy_if_less_than=32, matching_type=MatchingType.Lazy):
+        self.max_hash_checks = max_hash_checks
+        self.lazy_if_less_than = lazy_if_less_than
+        self.matching_type = MatchingType(matching_type)
+
+    @staticmethod
+    def default():
+        return CompressionOptions(128, 32, MatchingType.Lazy)
+
+    @staticmethod
+    def high():
+        return CompressionOptions(1768, 128, MatchingType.Lazy)
+
+    @staticmethod
+    def fast():
+        return CompressionOptions(1, 0, MatchingType.Greedy)
+
+    @staticmethod
+    def huffman_only():
+        return CompressionOptions(0, 0, MatchingType.Greedy)
+
+    @staticmethod
+    def rle():
+        return CompressionOptions(0, 0, MatchingType.Lazy)
+
+    @staticmethod
+    def from_(o):
+        """impl From<Compression> for CompressionOptions (:188-196)"""
+        if isinstance(o, CompressionOptions):
+            return o
+        o = Compression(o)
+        return {Compression.Fast: CompressionOptions.fast, Compression.Default: CompressionOptions.default,
+                Compression.Best: CompressionOptions.high}[o]()
+
+    def to_c(self, wrapper=0, compat=0):
+        return Opts(self.max_hash_checks, self.lazy_if_less_than, int(self.matching_type), wrapper, compat, 0)
+
+
+class DeflateError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mi355_deflate error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libmi355deflate.so.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmi355deflate.so is missing (%s); run __graft_entry__.build() or "
+                          "`make -C deflate-rs_amd` -- there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    u8p = C.POINTER(C.c_uint8)
+    L.mi355_deflate_version.restype = C.c_int
+    L.mi355_deflate_bound.argtypes = [C.c_size_t]
+    L.mi355_deflate_bound.restype = C.c_size_t
+    L.mi355_deflate_preset.argtypes = [C.c_int, C.POINTER(Opts)]
+    L.mi355_deflate_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mi355_deflate_ctx_destroy.argtypes = [C.c_void_p]
+    L.mi355_deflate_ctx_destroy.restype = None
+    L.mi355_deflate_last_error.argtypes = [C.c_void_p]
+    L.mi355_deflate_last_error.restype = C.c_char_p
+    L.mi355_deflate_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(Opts), u8p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
+    L.mi355_deflate_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_void_p,
+                                              C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.mi355_deflate_last_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    L.mi355_deflate_last_blocks.argtypes = [C.c_void_p, C.POINTER(BlockInfo), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_adler32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
+    L.mi355_deflate_stream_new.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
+    L.mi355_deflate_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mi355_deflate_stream_finish.argtypes = [C.c_void_p]
+    L.mi355_deflate_stream_output.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t)]
+    L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
+    L.mi355_deflate_stream_free.restype = None
+    _lib = L
+    return L
+
+
+EXPORTED = [
+    "mi355_deflate_version", "mi355_deflate_bound", "mi355_deflate_preset", "mi355_deflate_ctx_create",
+    "mi355_deflate_ctx_destroy", "mi355_deflate_last_error", "mi355_deflate_encode",
+    "mi355_deflate_encode_device", "mi355_deflate_last_info", "mi355_deflate_last_blocks", "mi355_adler32_device",
+    "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_finish",
+    "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
+]
+
+
+class Context:
+    """One HIP device + workspace (mi355_deflate_ctx)."""
+
+    def __init__(self, device=0):
+        L = load()
+        h = C.c_void_p()
+        rc = L.mi355_deflate_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise DeflateError(rc, "cannot create a context on HIP device %d (no GPU? no CPU fallback exists)"
+                               % device)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mi355_deflate_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
+
+    def encode(self, data, options=Compression.Default, wrapper=0, compat=0):
+        """Host bytes in, host bytes out (mi355_deflate_encode)."""
+        L = load()
+        o = CompressionOptions.from_(options).to_c(wrapper, compat)
+        data = bytes(data)
+        cap = L.mi355_deflate_bound(len(data)) + 16
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_encode(self._h, data, len(data), C.byref(o), out, cap, C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return bytes(memoryview(out)[: n.value])
+
+    def encode_device(self, d_in_ptr, in_len, d_out_ptr, out_cap, options=Compression.Default, wrapper=0,
+                      compat=0, stream=0):
+        """Device pointers in/out (mi355_deflate_encode_device); returns the output length."""
+        L = load()
+        o = CompressionOptions.from_(options).to_c(wrapper, compat)
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_encode_device(self._h, C.c_void_p(d_in_ptr), in_len, C.byref(o), C.c_void_p(d_out_ptr),
+                                           out_cap, C.byref(n), C.c_void_p(stream))
+        if rc != OK:
+            self._err(rc)
+        return n.value
+
+    def info(self):
+        i = Info()
+        load().mi355_deflate_last_info(self._h, C.byref(i))
+        d = {k: getattr(i, k) for k, _ in Info._fields_ if k not in ("stage_ms", "reserved")}
+        d["stage_ms"] = {STAGES[k]: i.stage_ms[k] for k in range(6)}
+        return d
+
+    def blocks(self):
+        """Block layout of the last encode, same dict shape as the oracle's trace."""
+        L = load()
+        n = C.c_size_t(0)
+        L.mi355_deflate_last_blocks(self._h, None, 0, C.byref(n))
+        arr = (BlockInfo * max(n.value, 1))()
+        rc = L.mi355_deflate_last_blocks(self._h, arr, n.value, C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return [dict(btype=a.btype, bfinal=a.bfinal, n_lz=a.n_tokens, in_bytes=a.in_bytes, bit_start=a.bit_start)
+                for a in arr[: n.value]]
+
+    def adler32_device(self, d_ptr, n, stream=0):
+        a = C.c_uint32(0)
+        rc = load().mi355_adler32_device(self._h, C.c_void_p(d_ptr), n, C.byref(a), C.c_void_p(stream))
+        if rc != OK:
+            self._err(rc)
+        return a.value
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+def bound(n):
+    return load().mi355_deflate_bound(n)
+
+
+# ---- the reference's one-shot functions (src/lib.rs) -------------------------------------------
+def deflate_bytes_conf(data, options, ctx=None):
+    """src/lib.rs:137-147"""
+    return (ctx or default_context()).encode(data, options, wrapper=0)
+
+
+def deflate_bytes(data, ctx=None):
+    """src/lib.rs:163-165"""
+    return deflate_bytes_conf(data, Compression.Default, ctx)
+
+
+def deflate_bytes_zlib_conf(data, options, ctx=None):
+    """src/lib.rs:182-198"""
+    return (ctx or default_context()).encode(data, options, wrapper=1)
+
+
+def deflate_bytes_zlib(data, ctx=None):
+    """src/lib.rs:216-218"""
+    return deflate_bytes_zlib_conf(data, Compression.Default, ctx)
+
+
+# ---- the reference's Write encoders (src/writer.rs) ---------------------------------------------
+class _Encoder:
+    _wrapper = 0
+
+    def __init__(self, writer, options=Compression.Default, ctx=None):
+        """::new(writer, options) (writer.rs:93-99, 189-199); `writer` needs a .write(bytes)."""
+        self._ctx = ctx or default_context()
+        self._w = writer
+        o = CompressionOptions.from_(options).to_c(self._wrapper, 0)
+        h = C.c_void_p()
+        rc = load().mi355_deflate_stream_new(self._ctx._h, C.byref(o), C.byref(h))
+        if rc != OK:
+            raise DeflateError(rc, "stream_new")
+        self._s = h
+
+    def write(self, buf):
+        """io::Write::write (always consumes everything, like write_all)"""
+        buf = bytes(buf)
+        rc = load().mi355_deflate_stream_write(self._s, buf, len(buf))
+        if rc != OK:
+            raise DeflateError(rc, "stream_write")
+        return len(buf)
+
+    write_all = write
+
+    def finish(self):
+        """finish(self) -> W (writer.rs:103-108, 209-214)"""
+        L = load()
+        rc = L.mi355_deflate_stream_finish(self._s)
+        if rc != OK:
+            raise DeflateError(rc, L.mi355_deflate_last_error(self._ctx._h).decode())
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        L.mi355_deflate_stream_output(self._s, C.byref(p), C.byref(n))
+        self._w.write(C.string_at(p, n.value) if n.value else b"")
+        return self._w
+
+    def __del__(self):
+        if getattr(self, "_s", None):
+            try:
+                load().mi355_deflate_stream_free(self._s)
+            except Exception:
+                pass
+            self._s = None
+
+
+class DeflateEncoder(_Encoder):
+    """write::DeflateEncoder (src/writer.rs:89-152)"""
+    _wrapper = 0
+
+
+class ZlibEncoder(_Encoder):
+    """write::ZlibEncoder (src/writer.rs:183-290)"""
+    _wrapper = 1
+
+    def checksum(self):
+        """src/writer.rs:248-250"""
+        a = C.c_uint32(0)
+        rc = load().mi355_deflate_stream_checksum(self._s, C.byref(a))
+        if rc != OK:
+            raise DeflateError(rc, "stream_checksum")
+        return a.value

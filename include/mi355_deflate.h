@@ -1,0 +1,156 @@
+/*
+ * mi355_deflate.h -- C ABI of the MI355X-native DEFLATE encode path (libmi355deflate.so).
+ *
+ * Drop-in boundary for the hot path of image-rs/deflate-rs v1.0.0.  The reference has no FFI
+ * seam (src/lib.rs:50 forbids unsafe code); the natural seam is its block driver
+ *     compress_data_dynamic_n(input, &mut DeflateState<W>, Flush)      src/compress.rs:80-84
+ * as called by compress_until_done (src/writer.rs:15-23) from compress_data_dynamic
+ * (src/lib.rs:110-122) and by the Write impls (src/writer.rs:124-127, 254-267).  Each entry
+ * point below names the reference item it replaces.  INTEGRATION.md shows the Rust shim a
+ * maintainer would add on the reference side.
+ *
+ * All functions are extern "C", take plain pointers and sizes, never throw, never abort, and
+ * return 0 on success or a negative MI355_E_* code.  There is NO CPU fallback: every encode
+ * runs the HIP kernels and fails with MI355_E_HIP if no gfx950 device is usable.
+ */
+#ifndef MI355_DEFLATE_H
+#define MI355_DEFLATE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_DEFLATE_VERSION 100 /* 0.1.0 */
+
+#define MI355_OK 0
+#define MI355_E_ARG (-1)           /* null pointer / bad option */
+#define MI355_E_OUT_TOO_SMALL (-2) /* *out_len holds the size needed */
+#define MI355_E_HIP (-3)           /* HIP runtime error; see mi355_deflate_last_error */
+#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching, or
+                                      input >= 4 GiB - 64 KiB in one call */
+#define MI355_E_REF_PANIC (-5)     /* the reference itself panics on this input (A.4 Q13, slice out
+                                      of range) and MI355_COMPAT_Q13 was requested */
+#define MI355_E_STATE (-6)         /* stream used after finish */
+
+/* CompressionOptions (src/compression_options.rs:78-120) + MatchingType (src/lz77.rs:27-37).
+ * `special` has only the Normal variant reachable from the public API and is omitted. */
+typedef struct {
+    uint16_t max_hash_checks;   /* compression_options.rs:84 */
+    uint16_t lazy_if_less_than; /* :101; clamped to 32768 like deflate_state.rs:105 */
+    uint8_t matching_type;      /* 0 = MatchingType::Greedy, 1 = MatchingType::Lazy */
+    uint8_t wrapper;            /* 0 = raw deflate (deflate_bytes_conf, DeflateEncoder),
+                                   1 = zlib: 78 9C + Adler-32 BE (deflate_bytes_zlib_conf,
+                                   ZlibEncoder; src/lib.rs:182-198, src/zlib.rs:59-62) */
+    uint8_t compat;             /* MI355_COMPAT_* bits */
+    uint8_t reserved;
+} mi355_deflate_opts;
+
+/* Bug-for-bug mode for SURVEY A.4 Q13: when a Stored block ends on a match that crosses the
+ * end of a non-first window, the reference reads the stored bytes 32768 too far ahead
+ * (src/lz77.rs:679-695 + src/compress.rs:230-245) and emits a stream that does NOT inflate to
+ * the input.  Default (bit clear): emit the block's real bytes (valid stream; differs from the
+ * reference only inside that block).  Bit set: reproduce the reference's bytes exactly. */
+#define MI355_COMPAT_Q13 1u
+
+/* Compression::{Fast, Default, Best} -> CompressionOptions (compression_options.rs:188-196)
+ * and the two named profiles rle() :171-178, huffman_only() :155-162. */
+#define MI355_LEVEL_FAST 0
+#define MI355_LEVEL_DEFAULT 1
+#define MI355_LEVEL_BEST 2
+#define MI355_LEVEL_RLE 3
+#define MI355_LEVEL_HUFFMAN_ONLY 4
+int mi355_deflate_preset(int level, mi355_deflate_opts* out);
+
+int mi355_deflate_version(void);
+
+/* Upper bound of the output size for in_len input bytes (all-stored worst case + framing). */
+size_t mi355_deflate_bound(size_t in_len);
+
+/* A context owns one HIP device, its workspace and timing events.  Not thread safe; use one
+ * context per thread (the reference's encoders are likewise single-owner: DeflateState,
+ * src/deflate_state.rs:66-97). */
+typedef struct mi355_deflate_ctx mi355_deflate_ctx;
+int mi355_deflate_ctx_create(int device, mi355_deflate_ctx** out);
+void mi355_deflate_ctx_destroy(mi355_deflate_ctx* ctx);
+const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
+
+/* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
+ * in, host buffer out.  ctx may be NULL (a process-wide default context on device 0 is used,
+ * mutex guarded). */
+int mi355_deflate_encode(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
+                         uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* Same computation with input and output resident in device memory (no PCIe in the path):
+ * compress_data_dynamic + compress_until_done(.., Flush::Finish) (src/lib.rs:110-122,
+ * src/writer.rs:15-58) over d_in[0..in_len).  d_out needs mi355_deflate_bound(in_len) bytes
+ * (+4 slack, rounded up to 4).  `hip_stream` is a hipStream_t (NULL = default stream); the
+ * call returns after the stream has drained, with *out_len set.  Always raw deflate unless
+ * opts->wrapper == 1, in which case the 2-byte header and 4-byte trailer are written too. */
+int mi355_deflate_encode_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, const mi355_deflate_opts* opts,
+                                void* d_out, size_t out_cap, size_t* out_len, void* hip_stream);
+
+/* What the last encode on this context did (also the hook bench.py reads its HIP-event timings
+ * from). */
+#define MI355_STAGE_LINKS 0   /* k_links        (chained_hash_table.rs) */
+#define MI355_STAGE_MATCH 1   /* k_match/k_rle  (matching.rs, rle.rs) */
+#define MI355_STAGE_PARSE 2   /* k_adv .. k_compact (lz77.rs parsers as a restart path) */
+#define MI355_STAGE_BLOCKS 3  /* bounds, histogram, header, plan (output_writer.rs, huffman_lengths.rs) */
+#define MI355_STAGE_PACK 4    /* k_pack         (encoder_state.rs, bitstream.rs, stored_block.rs) */
+#define MI355_STAGE_OTHER 5   /* memset, adler, copies */
+#define MI355_N_STAGES 6
+typedef struct {
+    uint64_t in_len, out_len;
+    uint64_t n_tokens;
+    uint32_t n_blocks, n_stored, n_fixed, n_dynamic;
+    uint32_t q1_rewarm;       /* 1 if the hash re-warm quirk (A.4 Q1) fired and was reproduced */
+    uint32_t q13_hits;        /* stored blocks hit by A.4 Q13 */
+    uint32_t passes;          /* 1, or 2 when Q1 forced a second pass */
+    uint32_t reserved;
+    float stage_ms[MI355_N_STAGES]; /* HIP-event time per stage, summed over passes */
+    float total_ms;                 /* first kernel enqueued .. last kernel done */
+    uint32_t match_launches;        /* launches of the dominant kernel in this encode */
+    float match_ms;                 /* their summed duration */
+} mi355_deflate_info;
+int mi355_deflate_last_info(mi355_deflate_ctx* ctx, mi355_deflate_info* info);
+
+/* Diagnostics: the block layout of the last encode (type, BFINAL, tokens, input bytes, bit offset
+ * of the first header bit inside the raw deflate stream) -- the per-block facts of
+ * compress_data_dynamic_n's loop (src/compress.rs:157-246), for diffing against an oracle. */
+typedef struct {
+    uint32_t btype; /* 0 stored, 1 fixed, 2 dynamic */
+    uint32_t bfinal;
+    uint32_t n_tokens;
+    uint32_t reserved;
+    uint64_t in_bytes;
+    uint64_t bit_start;
+} mi355_block_info;
+int mi355_deflate_last_blocks(mi355_deflate_ctx* ctx, mi355_block_info* out, size_t cap, size_t* n_blocks);
+
+/* Adler-32 of a device buffer (crate adler32's RollingAdler32::update_buffer as used by
+ * src/checksum.rs:33-57), computed on the GPU. */
+int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, uint32_t* adler, void* hip_stream);
+
+/* Streaming encoder mirroring write::{DeflateEncoder, ZlibEncoder}<W> (src/writer.rs:89-290):
+ *   _new      = ::new(W, options)                    :93-99 / :189-199
+ *   _write    = io::Write::write_all                 :124-127 / :254-267
+ *   _finish   = finish(self) -> W                    :103-108 / :209-214
+ *   _output   = the bytes W = Vec<u8> would hold
+ *   _checksum = ZlibEncoder::checksum()              :248-250
+ * Output is independent of how the input is split across writes (the reference guarantees the
+ * same: src/lz77.rs:627, test src/lib.rs:408-433), so writes are gathered and encoded on the
+ * GPU at finish().  flush() (Flush::Sync) and reset() are not implemented in this round. */
+typedef struct mi355_deflate_stream mi355_deflate_stream;
+int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* opts, mi355_deflate_stream** out);
+int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);
+int mi355_deflate_stream_finish(mi355_deflate_stream* s);
+int mi355_deflate_stream_output(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
+int mi355_deflate_stream_checksum(mi355_deflate_stream* s, uint32_t* adler);
+void mi355_deflate_stream_free(mi355_deflate_stream* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

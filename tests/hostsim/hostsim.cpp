@@ -297,7 +297,8 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
         const uint32_t* pd = df;
         build_block_header(pl, pd, hdr[b], scratch);
         uint64_t in_bytes = bstart[b + 1] - bstart[b];
-        plan_block(hdr[b], in_bytes, b + 1 == nb, bitpos, &plan[b]);
+        plan_block(hdr[b].dyn_bits, hdr[b].dyn_est, hdr[b].static_est, hdr[b].fixed_bits, in_bytes, b + 1 == nb, bitpos,
+                   &plan[b]);
         // Q13: a full block whose last value is a match crossing the end of a
         // non-first window makes the reference slide before it reads the stored bytes.
         if (plan[b].btype == BT_STORED && t1 - t0 == MAX_BUFFER_LENGTH) {
