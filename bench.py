@@ -1,0 +1,157 @@
+"""bench.py -- MB/s of raw input encoded at Compression::Default on MI355X, next to the CPU oracle.
+
+One step = one pass of the whole encode path (links -> match -> parse -> blocks -> pack, plus the
+stitch on N > 1) over one batch of synthetic input that is already resident in HBM.  Contract: see
+the task statement; prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json configs): "enwik8" = 100 000 000 bytes of enwik8-like text, Default,
+dynamic-Huffman blocks (the configuration the metric is quoted on; default); "zeros" = 256 MiB zero
+fill through the RLE path (config 2); "random" = 64 MiB noise (stored blocks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_input(workload, size, rank):
+    import datagen
+    if workload == "enwik8":
+        return datagen.text_like(size, 0x656E77696B38 ^ rank)
+    if workload == "zeros":
+        return bytes(size)
+    if workload == "random":
+        return datagen.rng_bytes(size, 0x5EED0001 ^ rank)
+    raise SystemExit("unknown workload " + workload)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random"])
+    ap.add_argument("--size", type=int, default=0, help="bytes per GPU (0 = the config's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import deflate_amd as da
+    import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    size = args.size or {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024}[args.workload]
+    options = da.CompressionOptions.rle() if args.workload == "zeros" else da.CompressionOptions.default()
+    level_name = "rle()" if args.workload == "zeros" else "Compression::Default"
+
+    data = make_input(args.workload, size, rank)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = da.bound(size) + 8
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    ctx = da.Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    flush = shard.flush_mode_for(rank, world)
+
+    out_len = [0]
+    match_ms = []
+    stage_ms = {}
+    gpu_ms = []
+
+    def step(record):
+        n = ctx.encode_device(d_in.data_ptr(), size, d_out.data_ptr(), cap, options, stream=stream, flush=flush)
+        out_len[0] = n
+        if record:
+            info = ctx.info()
+            match_ms.append(info["match_ms"] / max(1, info["match_launches"]))
+            gpu_ms.append(info["total_ms"])
+            for k, v in info["stage_ms"].items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+        if world > 1:
+            shard.stitch(d_out, n, rank, world)
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot_out = torch.tensor([out_len[0]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot_out)
+        total_out = int(tot_out.item())
+    else:
+        total_out = out_len[0]
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * size * args.steps / elapsed / 1e6
+        mm = sum(match_ms) / len(match_ms)
+        dominant = "k_rle" if args.workload == "zeros" else "k_match"
+        algo_bytes = size + out_len[0]  # 1 B read + r B written per input byte, one launch = one input
+        achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0
+        res = {
+            "metric": "MB/s raw input encoded (Compression::Default) + compressed size vs ref",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: %d bytes per GPU, %s, stream-exact (P1) per GPU%s" % (
+                args.workload, size, level_name, "" if world == 1 else ", chunk-exact (P2) stitch across GPUs"),
+                "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % world},
+            "out_bytes": total_out, "ratio": round(total_out / (world * size), 5),
+            "gpu_ms_per_step_events": round(sum(gpu_ms) / len(gpu_ms), 3),
+            "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_binding as ob
+            lvl = ob.RLE if args.workload == "zeros" else ob.DEFAULT
+            sample = data if args.workload != "zeros" else data
+            t1 = time.perf_counter()
+            ref = ob.encode(sample, level=lvl)
+            dt = time.perf_counter() - t1
+            got = bytes(d_out[: out_len[0]].cpu().numpy())
+            res["cpu_baseline"] = {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                                   "sample": "the whole %d-byte workload, one pass of the single-threaded C++ "
+                                             "restatement of deflate-rs (oracle/), %.1f s" % (len(sample), dt)}
+            res["ref_out_bytes"] = len(ref)
+            res["bit_exact_vs_oracle"] = bool(got == ref)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -512,9 +512,12 @@ __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const
 // huffman_lengths.rs:269), bit offsets, BFINAL.  One wave; each lane loads one block, the wave
 // then steps through its 64 blocks in order.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint64_t bits, uint32_t nbits);
+
 __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
                                              const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
-                                             BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat) {
+                                             BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
+                                             uint32_t sync_tail, uint32_t* __restrict__ out32) {
     const uint32_t lane = threadIdx.x;
     const uint32_t nb = sc->nb;
     uint64_t bitpos = bit_base;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             uint64_t len = 0;
             if (lane == sidx) {
                 BlockPlan p;
-                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb, bitpos, &p);
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == nb) && !sync_tail, bitpos, &p);
                 plan[b] = p;
                 len = p.bit_len;
                 if (p.btype == BT_STORED) {
@@ -564,6 +567,11 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         panic |= __shfl_down(panic, off);
     }
     if (lane == 0) {
+        if (sync_tail) {  // compress.rs:256-261: empty stored block = 3 zero bits, pad, 00 00 FF FF
+            uint64_t hb = (bitpos + 3 + 7) & ~7ull;
+            put_bits(out32, hb, 0xFFFF0000ull, 32);
+            bitpos = hb + 32;
+        }
         sc->total_bits = bitpos - bit_base;
         sc->n_stored = n_st;
         sc->n_fixed = n_fx;
@@ -767,11 +775,12 @@ __global__ void k_adler_fold(uint32_t n, uint32_t nchunks, const uint32_t* __res
 }
 
 // zlib framing written on the device (lib.rs:182-198, zlib.rs:59-62): 78 9C, Adler-32 BE.
-__global__ void k_zlib_frame(DevScalars* sc, uint8_t* out) {
+__global__ void k_zlib_frame(DevScalars* sc, uint8_t* out, uint32_t trailer) {
     if (threadIdx.x || blockIdx.x) return;
     uint64_t nbytes = (sc->total_bits + 7) / 8;
     out[0] = 0x78;
     out[1] = 0x9C;
+    if (!trailer) return;
     uint32_t a = sc->adler;
     out[2 + nbytes + 0] = (uint8_t)(a >> 24);
     out[2 + nbytes + 1] = (uint8_t)(a >> 16);

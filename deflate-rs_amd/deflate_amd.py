@@ -13,6 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355deflate.so")
 
+FLUSH_FINISH, FLUSH_SYNC = 0, 1
 OK, E_ARG, E_OUT_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_REF_PANIC, E_STATE = 0, -1, -2, -3, -4, -5, -6
 COMPAT_Q13 = 1
 
@@ -22,7 +23,7 @@ STAGES = ["links", "match", "parse", "blocks", "pack", "other"]
 class Opts(C.Structure):
     _fields_ = [("max_hash_checks", C.c_uint16), ("lazy_if_less_than", C.c_uint16),
                 ("matching_type", C.c_uint8), ("wrapper", C.c_uint8), ("compat", C.c_uint8),
-                ("reserved", C.c_uint8)]
+                ("flush", C.c_uint8)]
 
 
 class Info(C.Structure):
@@ -88,8 +89,8 @@ class CompressionOptions:
         return {Compression.Fast: CompressionOptions.fast, Compression.Default: CompressionOptions.default,
                 Compression.Best: CompressionOptions.high}[o]()
 
-    def to_c(self, wrapper=0, compat=0):
-        return Opts(self.max_hash_checks, self.lazy_if_less_than, int(self.matching_type), wrapper, compat, 0)
+    def to_c(self, wrapper=0, compat=0, flush=0):
+        return Opts(self.max_hash_checks, self.lazy_if_less_than, int(self.matching_type), wrapper, compat, flush)
 
 
 class DeflateError(RuntimeError):
@@ -174,10 +175,10 @@ class Context:
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
 
-    def encode(self, data, options=Compression.Default, wrapper=0, compat=0):
+    def encode(self, data, options=Compression.Default, wrapper=0, compat=0, flush=0):
         """Host bytes in, host bytes out (mi355_deflate_encode)."""
         L = load()
-        o = CompressionOptions.from_(options).to_c(wrapper, compat)
+        o = CompressionOptions.from_(options).to_c(wrapper, compat, flush)
         data = bytes(data)
         cap = L.mi355_deflate_bound(len(data)) + 16
         out = (C.c_uint8 * cap)()
@@ -188,10 +189,10 @@ class Context:
         return bytes(memoryview(out)[: n.value])
 
     def encode_device(self, d_in_ptr, in_len, d_out_ptr, out_cap, options=Compression.Default, wrapper=0,
-                      compat=0, stream=0):
+                      compat=0, stream=0, flush=0):
         """Device pointers in/out (mi355_deflate_encode_device); returns the output length."""
         L = load()
-        o = CompressionOptions.from_(options).to_c(wrapper, compat)
+        o = CompressionOptions.from_(options).to_c(wrapper, compat, flush)
         n = C.c_size_t(0)
         rc = L.mi355_deflate_encode_device(self._h, C.c_void_p(d_in_ptr), in_len, C.byref(o), C.c_void_p(d_out_ptr),
                                            out_cap, C.byref(n), C.c_void_p(stream))

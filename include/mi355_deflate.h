@@ -45,8 +45,18 @@ typedef struct {
                                    1 = zlib: 78 9C + Adler-32 BE (deflate_bytes_zlib_conf,
                                    ZlibEncoder; src/lib.rs:182-198, src/zlib.rs:59-62) */
     uint8_t compat;             /* MI355_COMPAT_* bits */
-    uint8_t reserved;
+    uint8_t flush;              /* MI355_FLUSH_FINISH (0) or MI355_FLUSH_SYNC (1) */
 } mi355_deflate_opts;
+
+/* How the stream ends (src/compress.rs:18-30 Flush).  FINISH: the last block carries BFINAL
+ * (compress_until_done(.., Flush::Finish), what deflate_bytes_conf and finish() do).  SYNC: what a
+ * fresh encoder has written after write_all(input) + flush() (src/writer.rs:134-137): every block
+ * non-final, then the empty stored block 00 00 FF FF (src/compress.rs:256-261).  The output is byte
+ * aligned, so SYNC chunks followed by one FINISH chunk concatenate into one valid deflate stream --
+ * the chunk-exact ("P2") stitch used to shard one input over several GPUs.  With wrapper = 1 the
+ * zlib trailer is only written for FINISH. */
+#define MI355_FLUSH_FINISH 0
+#define MI355_FLUSH_SYNC 1
 
 /* Bug-for-bug mode for SURVEY A.4 Q13: when a Stored block ends on a match that crosses the
  * end of a non-first window, the reference reads the stored bytes 32768 too far ahead

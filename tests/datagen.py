@@ -27,30 +27,52 @@ def _vocab():
     return _WORDS
 
 
+_TABLE = None
+
+
+def _table():
+    """fixed-width byte rows: one per vocabulary word, markup token and separator"""
+    global _TABLE
+    if _TABLE is None:
+        words, markup = _vocab()
+        seps = [" ", " ", " ", " ", " ", " ", ", ", ". ", ".\n", " "]
+        rows = [w.encode() for w in words] + [m.encode() for m in markup] + [x.encode() for x in seps]
+        width = max(len(r) for r in rows)
+        mat = np.zeros((len(rows), width), dtype=np.uint8)
+        lens = np.zeros(len(rows), dtype=np.int64)
+        for i, r in enumerate(rows):
+            mat[i, :len(r)] = np.frombuffer(r, dtype=np.uint8)
+            lens[i] = len(r)
+        ranks = np.arange(1, len(words) + 1, dtype=np.float64)
+        p = ranks ** -1.07
+        p /= p.sum()
+        _TABLE = (mat, lens, len(words), len(markup), len(seps), np.cumsum(p))
+    return _TABLE
+
+
 def text_like(n, seed):
-    """enwik8-like text: Zipf(1.07) over a 50 000-word vocabulary, sentences, 5 % markup
-    (SURVEY.md 8d config 3).  Vectorised so that 100 MB generate in seconds."""
-    words, markup = _vocab()
+    """enwik8-like text: Zipf(1.07) over a 50 000-word vocabulary, sentences, 5 % markup tokens
+    (SURVEY.md 8d config 3).  Fully vectorised: 100 MB generate in a few seconds."""
+    mat, lens, nw, nm, ns, cdf = _table()
     rng = np.random.default_rng(seed)
-    ranks = np.arange(1, len(words) + 1, dtype=np.float64)
-    p = ranks ** -1.07
-    p /= p.sum()
-    enc = [w.encode() for w in words]
-    out = bytearray()
-    seps = [b" ", b" ", b" ", b" ", b" ", b" ", b", ", b". ", b".\n", b" "]
-    m_enc = [m.encode() for m in markup]
-    while len(out) < n:
-        k = 200000
-        idx = rng.choice(len(words), size=k, p=p)
-        sp = rng.integers(0, len(seps), size=k)
+    out = []
+    have = 0
+    col = np.arange(mat.shape[1])
+    while have < n:
+        k = 1 << 20
+        w = np.searchsorted(cdf, rng.random(k), side="right").clip(0, nw - 1)
         mk = rng.random(k) < 0.05
-        mi = rng.integers(0, len(m_enc), size=k)
-        parts = []
-        for i in range(k):
-            parts.append(m_enc[mi[i]] if mk[i] else enc[idx[i]])
-            parts.append(seps[sp[i]])
-        out += b"".join(parts)
-    return bytes(out[:n])
+        mi = rng.integers(0, nm, size=k) + nw
+        sp = rng.integers(0, ns, size=k) + nw + nm
+        tok = np.where(mk, mi, w)
+        rows = np.empty(2 * k, dtype=np.int64)
+        rows[0::2] = tok
+        rows[1::2] = sp
+        mask = col[None, :] < lens[rows][:, None]
+        chunk = mat[rows][mask]
+        out.append(chunk)
+        have += chunk.size
+    return np.concatenate(out)[:n].tobytes()
 
 
 def mixed(n, seed):

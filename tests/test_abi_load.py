@@ -1,0 +1,60 @@
+"""CPU-only: the product library loads and exports every symbol include/mi355_deflate.h declares;
+without a GPU it refuses to work instead of falling back to anything."""
+import os
+import re
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd"))
+
+
+def test_header_symbols_are_exported():
+    import deflate_amd
+    if not os.path.exists(deflate_amd.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "deflate-rs_amd"), "-s"])
+    L = deflate_amd.load()
+    hdr = open(os.path.join(ROOT, "include", "mi355_deflate.h")).read()
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(deflate_amd.EXPORTED)
+    assert L.mi355_deflate_version() >= 100
+    assert L.mi355_deflate_bound(0) >= 16
+
+
+def test_presets_match_reference_levels():
+    import deflate_amd
+    L = deflate_amd.load()
+    exp = {0: (1, 0, 0), 1: (128, 32, 1), 2: (1768, 128, 1), 3: (0, 0, 1), 4: (0, 0, 0)}
+    for lvl, (c, l, m) in exp.items():
+        o = deflate_amd.Opts()
+        assert L.mi355_deflate_preset(lvl, o) == 0
+        assert (o.max_hash_checks, o.lazy_if_less_than, o.matching_type) == (c, l, m)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import deflate_amd
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(deflate_amd.DeflateError):
+        deflate_amd.Context(0)
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "deflate-rs_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
+                src = open(os.path.join(base, f), errors="ignore").read()
+                assert "deflref" not in src and "oracle_binding" not in src and "hostsim" not in src.replace(
+                    "tests/hostsim", ""), f

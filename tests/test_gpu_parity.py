@@ -1,0 +1,288 @@
+"""Parity tests proper: the HIP path (through the C ABI of include/mi355_deflate.h) against the
+CPU oracle -- bit-exact, every level, the reference's own fixtures, edge sizes, quirks -- plus
+size-independent properties at BASELINE sizes.  Needs a real MI355X: pytest -m gpu."""
+import glob
+import os
+import sys
+import zlib
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd"))
+
+import datagen
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+FIX = os.path.join(HERE, "golden", "ref_inputs")
+LV = {"fast": (1, 0, 0), "default": (128, 32, 1), "best": (1768, 128, 1), "rle": (0, 0, 1),
+      "huffman_only": (0, 0, 0)}
+
+
+@pytest.fixture(scope="module")
+def da():
+    import deflate_amd
+    return deflate_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(da):
+    c = da.Context(0)
+    yield c
+    c.close()
+
+
+def inflate_raw(b):
+    d = zlib.decompressobj(-15)
+    out = d.decompress(b) + d.flush()
+    assert d.eof and d.unused_data == b""
+    return out
+
+
+def agree(da, ctx, data, c, l, m, compat=1):
+    ref = ob.encode(data, opts=ob.make_opts(c, l, m))
+    rb = ob.trace_blocks()
+    out = ctx.encode(data, da.CompressionOptions(c, l, m), compat=compat)
+    if out != ref:
+        bl = ctx.blocks()
+        diff = next((i for i, (a, b) in enumerate(zip(bl, rb)) if a != b), None)
+        raise AssertionError("HIP != oracle (%d vs %d bytes); first differing block %s: %s vs %s" % (
+            len(out), len(ref), diff, bl[diff] if diff is not None else None,
+            rb[diff] if diff is not None else None))
+    assert ctx.blocks() == rb
+    return ctx.info()
+
+
+def test_library_is_the_hip_one(da, ctx):
+    assert da.load().mi355_deflate_version() >= 100
+    assert os.path.exists(da.LIB_PATH)
+
+
+# tests/test.rs:36-56,93-111 + lib.rs:318-367: every level on pg11.txt -- here bit-exact, not just roundtrip
+@pytest.mark.parametrize("level", list(LV))
+def test_reference_fixtures_all_levels(da, ctx, level):
+    for f in ["pg11.txt", "short.bin", "issue_18_201911.bin", "dump.bin"]:
+        data = open(os.path.join(FIX, f), "rb").read()
+        info = agree(da, ctx, data, *LV[level])
+        assert info["in_len"] == len(data)
+
+
+# tests/test.rs:147-161 afl_regressions_default_compression (+ fast, as the fuzz target does)
+def test_afl_regressions(da, ctx):
+    files = sorted(glob.glob(os.path.join(FIX, "afl", "*")))
+    assert len(files) == 45
+    for f in files:
+        data = open(f, "rb").read()
+        agree(da, ctx, data, *LV["default"])
+        agree(da, ctx, data, *LV["fast"])
+
+
+# tests/test.rs:58-63 block_type, lib.rs:382-391 deflate_short, compress.rs:333-345
+def test_known_sizes(da, ctx):
+    assert len(da.deflate_bytes_zlib(open(os.path.join(FIX, "short.bin"), "rb").read(), ctx)) == 30
+    assert len(da.deflate_bytes(bytes([10, 10, 10, 10, 10, 55]), ctx)) == 5
+    assert da.deflate_bytes(b"", ctx) == b"\x03\x00"
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 6, 258, 259, 260, 8191, 8192, 8193, 31743, 31744, 31745, 32767,
+                               32768, 32769, 65535, 65536, 65537, 65794, 65795, 100000])
+def test_edge_sizes(da, ctx, n):
+    for level in LV:
+        agree(da, ctx, bytes(n), *LV[level])
+        agree(da, ctx, bytes(i & 0xFF for i in range(n)), *LV[level])
+
+
+def test_random_block_fill_q1_q8(da, ctx):
+    hit_q1 = 0
+    for n in (31744, 31745, 63488, 63489, 95232, 100000, 300000):
+        data = datagen.rng_bytes(n, n)
+        for level in LV:
+            hit_q1 += agree(da, ctx, data, *LV[level])["q1_rewarm"]
+    assert hit_q1 > 0  # the hash re-warm quirk (lz77.rs:628-638) must have fired and been reproduced
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mixed_inputs(da, ctx, seed):
+    data = datagen.mixed([50000, 140000, 300000, 1000000, 70000, 2000000][seed], seed)
+    for level in LV:
+        if level == "best" and len(data) > 400000:
+            data_l = data[:400000]
+        else:
+            data_l = data
+        agree(da, ctx, data_l, *LV[level])
+
+
+def test_text_like(da, ctx):
+    data = datagen.text_like(4_000_000, 7)
+    agree(da, ctx, data, *LV["default"])
+    agree(da, ctx, data, *LV["fast"])
+    agree(da, ctx, data[:500000], *LV["best"])
+
+
+def test_custom_options(da, ctx):
+    import random
+    rnd = random.Random(42)
+    data = datagen.mixed(200000, 99)
+    for _ in range(12):
+        c = rnd.choice([1, 2, 3, 7, 32, 128, 500, 4000])
+        l = rnd.choice([3, 4, 8, 31, 32, 33, 64, 258, 1000, 40000])
+        m = rnd.choice([0, 1])
+        agree(da, ctx, data, c, l, m)
+
+
+def test_periodic_and_runs(da, ctx):
+    for data in (b"ab" * 70000, b"abc" * 50000, bytes(100) + b"x" + bytes(200000),
+                 datagen.rng_bytes(300, 5) * 500, datagen.rng_bytes(32768, 6) * 4,
+                 datagen.rng_bytes(32769, 7) * 3, datagen.rng_bytes(32767, 8) * 3):
+        for level in LV:
+            agree(da, ctx, data, *LV[level])
+
+
+def test_unsupported_and_errors(da, ctx):
+    with pytest.raises(da.DeflateError) as e:
+        ctx.encode(b"abc" * 100, da.CompressionOptions(16, 2, da.MatchingType.Lazy))
+    assert e.value.code == da.E_UNSUPPORTED
+
+
+# lib.rs:446-485 zlib roundtrips + checksum.rs: zlib framing and Adler-32 computed on the GPU
+def test_zlib_wrapper(da, ctx):
+    for data in (b"", b"a", open(os.path.join(FIX, "pg11.txt"), "rb").read(), datagen.rng_bytes(70000, 3),
+                 bytes(70000)):
+        z = da.deflate_bytes_zlib(data, ctx)
+        assert z == ob.encode(data, level=ob.DEFAULT, wrapper=1)
+        assert zlib.decompress(z) == data
+
+
+# writer.rs tests: ZlibEncoder / DeflateEncoder write_all + finish; lib.rs:408-433 chunk invariance
+@pytest.mark.parametrize("chunk", [1, 50, 400, 32768, 65794, 50000])
+def test_streaming_encoders(da, ctx, chunk):
+    import io
+    data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
+    if chunk == 1:
+        data = data[:20000]
+    for cls, wrapper in ((da.DeflateEncoder, 0), (da.ZlibEncoder, 1)):
+        enc = cls(io.BytesIO(), da.Compression.Default, ctx)
+        for i in range(0, len(data), chunk):
+            enc.write_all(data[i:i + chunk])
+        if wrapper:
+            assert enc.checksum() == zlib.adler32(data)
+        out = enc.finish().getvalue()
+        assert out == ob.encode(data, level=ob.DEFAULT, wrapper=wrapper)
+
+
+# bug-for-bug with MI355_COMPAT_Q13, a valid stream without
+def test_q13_modes(da, ctx):
+    from test_stages_vs_oracle import q13_case
+    hit = 0
+    for seed in range(1, 8):
+        d = q13_case(seed)
+        if d is None:
+            continue
+        ref = ob.encode(d, level=ob.DEFAULT)
+        if not ob.last_hazards():
+            continue
+        hit += 1
+        assert ctx.encode(d, da.Compression.Default, compat=da.COMPAT_Q13) == ref
+        assert ctx.info()["q13_hits"] >= 1
+        sane = ctx.encode(d, da.Compression.Default, compat=0)
+        assert inflate_raw(sane) == d and len(sane) == len(ref)
+        if hit >= 2:
+            break
+    assert hit >= 1
+
+
+# device-resident API through torch tensors (no host copies in the path)
+def test_device_api(da, ctx):
+    import torch
+    data = datagen.text_like(3_000_000, 11)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = da.bound(len(data)) + 8
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    n = ctx.encode_device(t.data_ptr(), len(data), out.data_ptr(), cap, da.Compression.Default,
+                          stream=torch.cuda.current_stream().cuda_stream)
+    got = bytes(out[:n].cpu().numpy())
+    assert got == ob.encode(data, level=ob.DEFAULT)
+    assert ctx.adler32_device(t.data_ptr(), len(data)) == zlib.adler32(data)
+    # unaligned device input pointer takes the byte-load path
+    n2 = ctx.encode_device(t.data_ptr() + 1, len(data) - 1, out.data_ptr(), cap, da.Compression.Default)
+    assert bytes(out[:n2].cpu().numpy()) == ob.encode(data[1:], level=ob.DEFAULT)
+
+
+# BASELINE config 2: 256 MiB zero fill, RLE path; oracle is fast on zeros so this stays bit-exact
+def test_config2_zero_fill_256mib(da, ctx):
+    import torch
+    n = 256 * 1024 * 1024
+    t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    cap = da.bound(n) + 8
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    k = ctx.encode_device(t.data_ptr(), n, out.data_ptr(), cap, da.CompressionOptions.rle())
+    got = bytes(out[:k].cpu().numpy())
+    info = ctx.info()
+    assert info["n_blocks"] == 33  # 1 literal + 1 040 448 matches -> 33 blocks of 31744 values
+    ref = ob.encode(bytes(n), level=ob.RLE)
+    assert got == ref
+    d = zlib.decompressobj(-15)
+    total = 0
+    buf = got
+    while buf:
+        piece = d.decompress(buf, 1 << 24)
+        assert piece.count(0) == len(piece)
+        total += len(piece)
+        buf = d.unconsumed_tail
+    assert total == n
+
+
+# BASELINE config 3 size (100 MB text, Default): size-independent properties -- inflate round trip,
+# every non-final block holds exactly 31744 tokens, sum of block bytes == input, plus bit-exactness of a
+# prefix-sized sample against the oracle
+def test_config3_full_size_properties(da, ctx):
+    import torch
+    n = 100_000_000
+    data = datagen.text_like(n, 0x656E77696B38)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = da.bound(n) + 8
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    k = ctx.encode_device(t.data_ptr(), n, out.data_ptr(), cap, da.Compression.Default)
+    got = bytes(out[:k].cpu().numpy())
+    bl = ctx.blocks()
+    assert all(b["n_lz"] == 31744 for b in bl[:-1])
+    assert sum(b["in_bytes"] for b in bl) == n
+    assert [b["bfinal"] for b in bl] == [0] * (len(bl) - 1) + [1]
+    assert zlib.crc32(inflate_raw(got)) == zlib.crc32(data)
+    # the stream for a 16 MB prefix is a different stream (BFINAL position) but must equal the oracle
+    m = 16_000_000
+    k2 = ctx.encode_device(t.data_ptr(), m, out.data_ptr(), cap, da.Compression.Default)
+    assert bytes(out[:k2].cpu().numpy()) == ob.encode(data[:m], level=ob.DEFAULT)
+
+
+# MI355_FLUSH_SYNC == fresh reference encoder: write_all(chunk); flush() (writer.rs:134-137,
+# compress.rs:256-261) -- the chunk form the multi-GPU stitch concatenates
+def test_sync_flush_chunks_and_stitch(da, ctx):
+    data = datagen.text_like(1_500_000, 21)
+    cuts = [0, 400000, 400001, 1_000_000, len(data)]
+    pieces = []
+    for i in range(len(cuts) - 1):
+        chunk = data[cuts[i]:cuts[i + 1]]
+        last = i == len(cuts) - 2
+        got = ctx.encode(chunk, da.Compression.Default, flush=da.FLUSH_FINISH if last else da.FLUSH_SYNC)
+        s = ob.Stream(ob.preset(ob.DEFAULT))
+        s.write_all(chunk)
+        if last:
+            exp = s.finish()
+        else:
+            s.flush()
+            exp = s.output()
+            assert exp.endswith(b"\x00\x00\xff\xff")
+        assert got == exp
+        pieces.append(got)
+    assert inflate_raw(b"".join(pieces)) == data
+    # zlib header on a sync chunk, no trailer
+    z = ctx.encode(data[:50000], da.Compression.Default, wrapper=1, flush=da.FLUSH_SYNC)
+    s = ob.Stream(ob.preset(ob.DEFAULT, 1))
+    s.write_all(data[:50000])
+    s.flush()
+    assert z == s.output()
