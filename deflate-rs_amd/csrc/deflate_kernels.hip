@@ -31,13 +31,23 @@ struct GM {  // match / run table in global memory
 struct LdsWin {  // the window of k_match: bytes and links in one window coordinate system
     const uint8_t* by;
     const uint16_t* lk;
+    // 4 bytes at any byte offset from two aligned dwords (one ds_read2_b32) + v_alignbyte: an
+    // unaligned ds_read_b32 works on gfx950 but is replayed lane by lane
     __device__ uint32_t load32(uint32_t i) const {
-        uint32_t v;
-        __builtin_memcpy(&v, by + i, 4);  // gfx950 LDS takes the unaligned ds_read_b32
-        return v;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(by) + (i >> 2);
+        uint32_t lo = w[0], hi = w[1];
+        return __builtin_amdgcn_alignbyte(hi, lo, i & 3);
     }
     __device__ uint32_t link(uint32_t i) const { return lk[i]; }
 };
+
+// Lanes of ONE wave handing data to each other through LDS: the hardware executes a wave's LDS
+// operations in order, so only the compiler has to be kept from moving or forwarding the accesses.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // scalars shared between kernels of one encode
 struct DevScalars {
@@ -58,107 +68,225 @@ constexpr uint32_t SEG = 1024;  // positions per level-0 segment
 constexpr uint32_t FAN = 32;    // children per unit in the table tree
 
 // ---------------------------------------------------------------------------------------------
-// k_links: chained_hash_table.rs:118-158 (add_hash_value) for every position, as "distance to
-// the most recent earlier position with the same hash".  One wave owns one 32 KiB epoch: it
-// replays the previous epoch to warm a 32768-entry last-occurrence table in LDS (64 KiB, u16
-// window-relative positions), then emits links for its own epoch.  Inside a 64-position batch
-// equal hashes are resolved with 15 ballots (peer mask), so the table is read once and written
-// once per batch without atomics.
+// k_links_a / k_links_b: chained_hash_table.rs:118-158 (add_hash_value) for every position, as
+// "distance to the most recent earlier position with the same hash".  The instruction-heavy part
+// (hash, equal-hash lanes inside a 64-position batch) needs no table and runs on the whole chip;
+// only the cross-batch part walks a table in order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_links(const uint8_t* __restrict__ in, uint32_t n, uint16_t* __restrict__ link,
-                                              HashOverride ov) {
+// 4 input bytes at p (zeros past the end), branch free so that the compiler can count the loads it
+// has in flight: one unaligned dword load from min(p, n-4), shifted.  Needs n >= 4.
+__device__ __forceinline__ uint32_t load_u32_clamped(const uint8_t* in, uint64_t p, uint64_t n) {
+    uint64_t q = p + 4 <= n ? p : n - 4;
+    uint32_t v;
+    __builtin_memcpy(&v, in + q, 4);
+    uint32_t sh = (uint32_t)(p - q) * 8;
+    return sh >= 32 ? 0u : v >> sh;
+}
+
+// Phase A (fully parallel, no table): per aligned batch of 64 positions the hashes, and by 15
+// ballots the mask of lanes with the same hash.  A lane with an equal hash below it gets its link
+// at once; `last` marks the lane that must publish its position to the table.
+__global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in, uint32_t n, uint16_t* __restrict__ link,
+                                                 uint16_t* __restrict__ hl, HashOverride ov) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n < 4) {
+        if (p < n) {
+            link[p] = 0;
+            hl[p] = 0;
+        }
+        return;
+    }
+    bool active = p + 2 < n;
+    uint32_t v = load_u32_clamped(in, p < n ? p : n - 1, n);
+    uint32_t a = v & 0xff, b1 = (v >> 8) & 0xff, c = (v >> 16) & 0xff;
+    if (ov.on) {
+        if (p == ov.pos) {
+            a = ov.b0;
+            b1 = ov.b1;
+        } else if (p == ov.pos + 1) {
+            a = ov.b1;
+        }
+    }
+    uint32_t h = active ? hash3(a, b1, c) : 0;
+    uint64_t peers = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+        uint64_t bal = __ballot(active && ((h >> b) & 1));
+        peers &= ((h >> b) & 1) ? bal : ~bal;
+    }
+    uint64_t lower = peers & ((1ull << lane) - 1ull);
+    uint32_t l = (active && lower) ? lane - (63u - (uint32_t)__builtin_clzll(lower)) : 0u;
+    uint32_t last = (active && ((peers >> lane) >> 1) == 0) ? 1u : 0u;
+    if (p < n) {
+        link[p] = (uint16_t)l;
+        hl[p] = (uint16_t)(h | (last << 15));
+    }
+}
+
+// Phase B: chained_hash_table.rs:148-158 across batches.  One wave owns one 32 KiB epoch and a
+// 32768-entry last-occurrence table in LDS (u16 window-relative positions); it replays the previous
+// epoch to warm the table, then resolves the lanes phase A left open (no equal hash below them in
+// their batch).  Per group of LG batches the table traffic is issued back to back in batch order --
+// read(g), write(g), read(g+1), ...: the LDS executes one wave's operations in order, so read(g+1)
+// sees write(g), the writes do not depend on the reads, and the wave waits once per group.
+constexpr int LG = 8;
+
+__global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict__ link,
+                                                const uint16_t* __restrict__ hl) {
     __shared__ uint16_t head[32768];
     const uint32_t lane = threadIdx.x;
     const uint64_t c0 = (uint64_t)blockIdx.x * WINDOW_SIZE;
     const int64_t base = (int64_t)c0 - WINDOW_SIZE;  // window-relative 0
     for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0xFFFF;
     __syncthreads();
-    GBytes by{in, n};
     uint64_t start = base < 0 ? 0 : (uint64_t)base;
     uint64_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;
-    for (uint64_t p0 = start; p0 < stop; p0 += 64) {
-        uint64_t p = p0 + lane;
-        bool active = p + 2 < n;
-        uint32_t h = active ? position_hash(by, p, ov) : 0;
-        uint64_t act = __ballot(active);
-        uint64_t peers = act;
+    const uint64_t nclamp = n - 1;
+    uint32_t chl[LG], clk[LG], nhl[LG], nlk[LG];
 #pragma unroll
-        for (int b = 0; b < 15; b++) {
-            uint64_t bal = __ballot(active && ((h >> b) & 1));
-            peers &= ((h >> b) & 1) ? bal : ~bal;
+    for (int g = 0; g < LG; g++) {
+        uint64_t p = start + 64 * g + lane;
+        uint64_t q = p < n ? p : nclamp;
+        chl[g] = hl[q];
+        clk[g] = link[q];
+    }
+    for (uint64_t p0 = start; p0 < stop; p0 += 64 * LG) {
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            uint64_t p = p0 + 64 * (LG + g) + lane;
+            uint64_t q = p < n ? p : nclamp;
+            nhl[g] = hl[q];
+            nlk[g] = link[q];
         }
-        uint64_t lower = peers & ((1ull << lane) - 1ull);
-        uint32_t rel = (uint32_t)((int64_t)p - base);  // 0..65535
-        uint32_t l = 0;
-        if (active) {
-            if (lower) {
-                l = lane - (63u - (uint32_t)__builtin_clzll(lower));
-            } else {
-                uint32_t stored = head[h];
-                if (stored < rel && rel - stored <= WINDOW_SIZE) l = rel - stored;
-            }
+        uint32_t stored[LG], rel[LG];
+        bool need[LG];
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            uint64_t p = p0 + 64 * g + lane;
+            bool active = p + 2 < n && p < stop;
+            uint32_t h = chl[g] & 0x7fff;
+            rel[g] = (uint32_t)((int64_t)p - base);  // 0..65535
+            need[g] = active && clk[g] == 0;
+            bool last = active && (chl[g] >> 15);
+            stored[g] = need[g] ? (uint32_t)head[h] : 0xFFFFu;
+            wave_lds_fence();
+            if (last) head[h] = (uint16_t)rel[g];
+            wave_lds_fence();
         }
-        if (p >= c0 && p < n) link[p] = (uint16_t)l;
-        __syncthreads();
-        if (active && ((peers >> lane) >> 1) == 0) head[h] = (uint16_t)rel;
-        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            uint64_t p = p0 + 64 * g + lane;
+            if (need[g] && p >= c0 && stored[g] < rel[g] && rel[g] - stored[g] <= WINDOW_SIZE)
+                link[p] = (uint16_t)(rel[g] - stored[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            chl[g] = nhl[g];
+            clk[g] = nlk[g];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_match: matching.rs:87-166 longest_match (prev_length = 0) for every position.  A workgroup
-// stages the 32 KiB history + its tile + 258 lookahead bytes and the links of the same range
-// in LDS (120 KiB) and each lane walks the chain of its own positions (match_walk).
+// stages the 32 KiB history + its 16 KiB tile + 258 lookahead bytes and the links of the same
+// range in LDS (144 KiB, one workgroup of 16 waves per CU); each lane owns 16 positions and keeps
+// four hash chains in flight (match_walk_multi).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t MT = 8192;                                // positions per tile
+constexpr uint32_t MT = 16384;                               // positions per tile
 constexpr uint32_t MTHREADS = 1024;
-constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // 41232, multiple of 16
+constexpr uint32_t MCHAINS = 4;                              // chains in flight per lane
+constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // 49424, multiple of 16
 constexpr uint32_t MW_LINKS = WINDOW_SIZE + MT;
 
+struct MatchEmit {
+    uint32_t* M;
+    uint32_t* Mq;
+    uint64_t wstart;
+    __device__ void operator()(uint32_t idx, uint32_t m, uint32_t mq) const {
+        M[wstart + idx] = m;
+        if (Mq) Mq[wstart + idx] = mq;
+    }
+};
+
+// positions of the tile are handed out through one LDS counter, so lanes stay busy until the tile is
+// done whatever their chain lengths were
+struct TileNext {
+    uint32_t* counter;
+    uint32_t base, count;
+    __device__ uint32_t operator()() {
+        uint32_t i = atomicAdd(counter, 1u);
+        return i < count ? base + i : (uint32_t)NO_POS;
+    }
+};
+// when to service parked / finished slots: every 8th step, or at once when no lane of the wave can
+// walk on (all lanes of a wave iterate in lockstep, so `iter` is uniform)
+struct WavePolicy {
+    __device__ bool operator()(bool pending, bool walking, uint32_t iter) const {
+        if ((iter & 7) == 7) return true;
+        return __ballot(walking) == 0;
+    }
+};
+
+template <bool HAS_Q>
 __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ in, uint32_t n,
                                                     const uint16_t* __restrict__ link, uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
                                                     int in_aligned4) {
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[MW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_link[MW_LINKS];
+    __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x;
     const uint64_t E = (uint64_t)blockIdx.x * MT;
     const uint64_t wstart = E >= WINDOW_SIZE ? E - WINDOW_SIZE : 0;
     uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_bytes);
-    for (uint32_t w = tid; w < MW_BYTES / 4; w += MTHREADS) {
-        uint64_t g = wstart + 4ull * w;
-        uint32_t v = 0;
-        if (in_aligned4 && g + 4 <= n) {
-            v = *reinterpret_cast<const uint32_t*>(in + g);
-        } else {
+    if (in_aligned4) {
+        for (uint32_t w = tid; w < MW_BYTES / 16; w += MTHREADS) {
+            uint64_t g = wstart + 16ull * w;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g + 16 <= n) {
+                v = *reinterpret_cast<const uint4*>(in + g);  // wstart is a multiple of 16
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16; b++)
+                    if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            reinterpret_cast<uint4*>(s_bytes)[w] = v;
+        }
+    } else {
+        for (uint32_t w = tid; w < MW_BYTES / 4; w += MTHREADS) {
+            uint64_t g = wstart + 4ull * w;
+            uint32_t v = 0;
             for (int b = 0; b < 4; b++)
                 if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
+            sb32[w] = v;
         }
-        sb32[w] = v;
     }
-    uint32_t* sl32 = reinterpret_cast<uint32_t*>(s_link);
-    for (uint32_t w = tid; w < MW_LINKS / 2; w += MTHREADS) {
-        uint64_t g = wstart + 2ull * w;
-        uint32_t v = 0;
-        if (g + 1 < n)
-            v = *reinterpret_cast<const uint32_t*>(link + g);  // wstart is even, link is 4-aligned
-        else if (g < n)
-            v = link[g];
-        sl32[w] = v;
+    for (uint32_t w = tid; w < MW_LINKS / 8; w += MTHREADS) {
+        uint64_t g = wstart + 8ull * w;  // link is 256-byte aligned and wstart a multiple of 8
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 8 <= n) {
+            v = *reinterpret_cast<const uint4*>(link + g);
+        } else {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 8; b++)
+                if (g + b < n) t[b >> 1] |= (uint32_t)link[g + b] << (16 * (b & 1));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        reinterpret_cast<uint4*>(s_link)[w] = v;
     }
+    if (tid == 0) s_next = 0;
     __syncthreads();
     LdsWin win{s_bytes, s_link};
-    for (uint32_t k = 0; k < MT / MTHREADS; k++) {
-        uint64_t p = E + tid + (uint64_t)k * MTHREADS;
-        if (p >= n) break;
-        uint32_t m = 0, mq = 0;
-        if (p + 2 < n) {
-            uint32_t max_len = n - p < MAX_MATCH ? (uint32_t)(n - p) : (uint32_t)MAX_MATCH;
-            match_walk(win, (uint32_t)(p - wstart), max_len, checks, checks_q, &m, &mq);
-        }
-        M[p] = m;
-        if (Mq) Mq[p] = mq;
-    }
+    MatchEmit emit{M, HAS_Q ? Mq : nullptr, wstart};
+    uint64_t nrel64 = (uint64_t)n - wstart;
+    uint32_t nrel = nrel64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nrel64;
+    TileNext next{&s_next, (uint32_t)(E - wstart), MT};
+    WavePolicy pol;
+    match_walk_park<MCHAINS, HAS_Q>(win, next, nrel, checks, checks_q, emit, pol);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -209,17 +337,52 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
 // k_seg_exit: for every position of a segment the first path position at or beyond the end of
 // the segment (right-to-left sweep), and the level-0 table over the segment's entry zone.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
-                                                 uint16_t* __restrict__ J, uint32_t* __restrict__ X0) {
-    uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
-    for (uint64_t j = b; j-- > a;) {
-        uint64_t t = j + adv[j];
-        J[j] = (uint16_t)(t >= b ? t - b : J[t]);
+// One wave per segment, right to left in chunks of 64 positions: a lane whose jump leaves the chunk
+// is resolved at once (from the table of the chunks already done, kept in LDS); jumps that stay
+// inside the chunk are resolved by pointer jumping across lanes (<= 7 rounds).
+__global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
+                                                  uint32_t* __restrict__ X0) {
+    __shared__ uint16_t sJ[4][SEG];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    if (k >= K) return;  // whole wave; no workgroup barrier is used below
+    uint16_t* J = sJ[wv];
+    const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    const uint32_t len = (uint32_t)(b - a);
+    for (int32_t c = (int32_t)((len - 1) / 64 * 64); c >= 0; c -= 64) {
+        uint32_t r = (uint32_t)c + lane;  // segment-relative position
+        bool valid = r < len;
+        uint32_t t = valid ? r + adv[a + r] : 0;
+        bool done = true;
+        uint32_t val = 0, tgt = lane;
+        if (valid) {
+            if (t >= len) {
+                val = t - len;
+            } else if (t >= (uint32_t)c + 64) {
+                val = J[t];
+            } else {
+                done = false;
+                tgt = t - (uint32_t)c;
+            }
+        }
+        while (__any(!done)) {
+            uint32_t tv = __shfl(val, (int)tgt);
+            int td = __shfl((int)done, (int)tgt);
+            uint32_t tt = __shfl(tgt, (int)tgt);
+            if (!done) {
+                if (td) {
+                    val = tv;
+                    done = true;
+                } else {
+                    tgt = tt;
+                }
+            }
+        }
+        if (valid) J[r] = (uint16_t)val;
+        wave_lds_fence();
     }
     uint32_t* x = X0 + k * ZONE;
-    for (uint32_t e = 0; e < ZONE; e++) x[e] = (a + e < b) ? (uint32_t)J[a + e] : (uint32_t)(a + e - b);
+    for (uint32_t e = lane; e < ZONE; e += 64) x[e] = e < len ? (uint32_t)J[e] : e - len;
 }
 
 // k_level_up: compose FAN child tables into one parent table.
@@ -262,24 +425,68 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
 // ---------------------------------------------------------------------------------------------
 // k_emit: walk each segment from its entry and write its tokens (output_writer.rs:47-65).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
-                                             const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
-                                             ParseCfg cfg, const uint32_t* __restrict__ E0,
-                                             uint32_t* __restrict__ tokbuf, uint32_t* __restrict__ cnt) {
-    uint64_t k = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+// One wave per segment: lane 0 follows adv[] from the segment's entry (the chain itself is serial,
+// but it now runs on LDS latency), then all lanes expand the path positions into tokens in parallel
+// and a wave scan places them.
+__global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
+                                              const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
+                                              ParseCfg cfg, const uint16_t* __restrict__ adv,
+                                              const uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
+                                              uint32_t* __restrict__ cnt) {
+    __shared__ uint16_t s_adv[4][SEG];
+    __shared__ uint16_t s_pp[4][SEG];
+    __shared__ uint32_t s_np[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    if (k >= K) return;  // whole wave; no workgroup barrier is used below
+    const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    const uint32_t len = (uint32_t)(b - a);
+    for (uint32_t r = lane; r < len; r += 64) s_adv[wv][r] = adv[a + r];
+    wave_lds_fence();
+    if (lane == 0) {
+        uint32_t np = 0;
+        uint64_t e = E0[k];
+        uint32_t j = e >= b ? len : (uint32_t)(e - a);
+        while (j < len) {
+            s_pp[wv][np++] = (uint16_t)j;
+            j += s_adv[wv][j];
+        }
+        s_np[wv] = np;
+    }
+    wave_lds_fence();
+    const uint32_t np = s_np[wv];
     GM m{M}, mq{Mq ? Mq : M};
     uint32_t* out = tokbuf + a;
-    uint32_t i = 0;
-    uint64_t j = E0[k];
-    while (j < b) {
-        Step st = parse_step(m, mq, j, (uint64_t)n, cfg);
-        for (uint32_t q = 0; q < st.nlit; q++) out[i++] = tok_literal(in[j + q]);
-        if (st.mlen) out[i++] = tok_match(st.mlen, st.mdist);
-        j += st.adv;
+    uint32_t running = 0;
+    for (uint32_t i0 = 0; i0 < np; i0 += 64) {
+        uint32_t idx = i0 + lane;
+        bool have = idx < np;
+        Step st;
+        st.nlit = 0;
+        st.mlen = 0;
+        st.mdist = 0;
+        st.adv = 0;
+        uint64_t j = 0;
+        if (have) {
+            j = a + s_pp[wv][idx];
+            st = parse_step(m, mq, j, (uint64_t)n, cfg);
+        }
+        uint32_t ntok = st.nlit + (st.mlen ? 1u : 0u);
+        uint32_t incl = ntok;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += v;
+        }
+        uint32_t total = __shfl(incl, 63);
+        if (have) {
+            uint32_t* o = out + running + (incl - ntok);
+            for (uint32_t q = 0; q < st.nlit; q++) o[q] = tok_literal(in[j + q]);
+            if (st.mlen) o[st.nlit] = tok_match(st.mlen, st.mdist);
+        }
+        running += total;
     }
-    cnt[k] = i;
+    if (lane == 0) cnt[k] = running;
 }
 
 // k_scan: exclusive scan of the per-segment token counts (single workgroup).

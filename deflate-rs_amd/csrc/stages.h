@@ -145,6 +145,290 @@ MI355_HD void match_walk(const W& w, uint32_t p, uint32_t max_len, uint32_t chec
     *out_mq = mq;
 }
 
+// The same walk for a lane that owns `count` positions first, first+stride, ...: U chains are
+// kept in flight at once (their LDS reads are independent, which hides the read latency a single
+// pointer chase exposes) and a finished chain is replaced at once by the lane's next position, so
+// lanes of a wave stay busy although chain lengths differ.  Results are identical to match_walk;
+// emit(idx, m, mq) is called once per position idx < nrel (nrel = end of input in W's index space).
+template <int U, bool HAS_Q, class W, class Emit>
+MI355_HD void match_walk_multi(const W& w, uint32_t first, uint32_t stride, uint32_t count, uint32_t nrel,
+                               uint32_t checks, uint32_t checks_q, Emit& emit) {
+    uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], mq[U], d[U], pv[U];
+    bool act[U], hq[U], cmp[U];
+    uint32_t knext = 0;
+    auto start = [&](int s) {
+        act[s] = false;
+        while (knext < count) {
+            uint32_t idx = first + knext * stride;
+            knext++;
+            if (idx >= nrel) continue;
+            if (idx + 2 >= nrel) {  // no hash byte: never searched (lz77.rs:294-301)
+                emit(idx, 0u, 0u);
+                continue;
+            }
+            p[s] = idx;
+            cand[s] = idx;
+            best[s] = 1;
+            bestd[s] = 0;
+            probe[s] = w.load32(idx) & 0xffffu;
+            it[s] = 0;
+            maxlen[s] = nrel - idx < (uint32_t)MAX_MATCH ? nrel - idx : (uint32_t)MAX_MATCH;
+            mq[s] = 0;
+            hq[s] = !HAS_Q;
+            act[s] = true;
+            return;
+        }
+    };
+    auto finish = [&](int s) {
+        uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
+        emit(p[s], m, hq[s] ? (HAS_Q ? mq[s] : m) : m);
+        start(s);
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < U; s++) start(s);
+    for (;;) {
+        bool any = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int s = 0; s < U; s++) any = any || act[s];
+        if (!any) break;
+        // A: the U independent link reads
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int s = 0; s < U; s++) d[s] = act[s] ? w.link(cand[s]) : 0u;
+        // B: chain end tests, then the U independent probe reads
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int s = 0; s < U; s++) {
+            cmp[s] = false;
+            if (!act[s]) continue;
+            if (HAS_Q && !hq[s] && it[s] == checks_q) {
+                mq[s] = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
+                hq[s] = true;
+            }
+            if (it[s] >= checks || d[s] == 0 || d[s] > cand[s]) {
+                finish(s);
+                continue;
+            }
+            cand[s] -= d[s];
+            if (p[s] - cand[s] > WINDOW_SIZE) {
+                finish(s);
+                continue;
+            }
+            pv[s] = w.load32(cand[s] + best[s] - 1) & 0xffffu;
+            cmp[s] = true;
+        }
+        // C: compare, extend on a hit
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int s = 0; s < U; s++) {
+            if (!cmp[s]) continue;
+            it[s]++;
+            if (pv[s] != probe[s]) continue;
+            uint32_t len = 0;
+            while (len < maxlen[s]) {
+                uint32_t x = w.load32(p[s] + len) ^ w.load32(cand[s] + len);
+                if (x) {
+                    len += ctz32(x) >> 3;
+                    break;
+                }
+                len += 4;
+            }
+            if (len > maxlen[s]) len = maxlen[s];
+            if (len > best[s]) {
+                best[s] = len;
+                bestd[s] = p[s] - cand[s];
+                if (len == maxlen[s]) {
+                    finish(s);
+                    continue;
+                }
+                probe[s] = w.load32(p[s] + len - 1) & 0xffffu;
+            }
+        }
+    }
+}
+
+// Third formulation of the same walk, shaped for gfx950: per chain step a slot issues BOTH reads
+// that depend on the current candidate together -- its link (the next candidate) and its probe
+// bytes -- so a step costs one LDS round trip, and U slots per lane overlap theirs.  Everything
+// that is rare per step is taken out of the step loop: a slot whose probe hits is PARKED, a slot
+// whose chain ended is FIN; only when `policy` says so (every 8th step on the GPU) the parked
+// slots are extended (get_match_length) in one dense loop and the finished ones report and take
+// the lane's next position from `next()`.  The common step stays ~25 VALU instructions per slot.
+// Results are identical to match_walk, including tie-breaks.
+enum : uint32_t { NO_POS = 0xFFFFFFFFu };
+
+struct ServiceAlways {  // host policy: service parked / finished slots at once
+    MI355_HD bool operator()(bool pending, bool /*walking*/, uint32_t /*iter*/) const { return pending; }
+};
+
+template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy>
+MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t checks, uint32_t checks_q, Emit& emit,
+                              const Policy& policy) {
+    enum : uint32_t { IDLE = 0, WALK = 1, PARK = 2, FIN = 3 };
+    uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], st[U], dsave[U], len[U], mq[U];
+    uint32_t rd[U], rv[U], ra[U], rb[U];
+    bool hq[U], ext[U], upd[U];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI355_UNROLL _Pragma("unroll")
+#else
+#define MI355_UNROLL
+#endif
+    // matching.rs:124-132: the loop header, the link and the two chain-end tests
+    auto follow = [&](int s, uint32_t d) {
+        st[s] = FIN;
+        if (it[s] >= checks) return;
+        if (HAS_Q && !hq[s] && it[s] == checks_q) {
+            mq[s] = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
+            hq[s] = true;
+        }
+        if (d == 0 || d > cand[s]) return;
+        uint32_t c = cand[s] - d;
+        if (p[s] - c > WINDOW_SIZE) return;
+        cand[s] = c;
+        it[s]++;
+        st[s] = WALK;
+    };
+    // a finished slot reports its result; then the slot takes positions until one has a candidate
+    auto retire = [&](int s) {
+        for (;;) {
+            if (st[s] == FIN) {
+                uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
+                emit(p[s], m, (HAS_Q && hq[s]) ? mq[s] : m);
+            }
+            st[s] = IDLE;
+            uint32_t idx = next();
+            if (idx == NO_POS) return;
+            if (idx >= nrel) continue;
+            if (idx + 2 >= nrel) {  // no hash byte: never searched (lz77.rs:294-301)
+                emit(idx, 0u, 0u);
+                continue;
+            }
+            p[s] = idx;
+            cand[s] = idx;
+            best[s] = 1;
+            bestd[s] = 0;
+            probe[s] = w.load32(idx) & 0xffffu;  // bytes 0,1 of P (matching.rs:110,141)
+            it[s] = 0;
+            maxlen[s] = nrel - idx < (uint32_t)MAX_MATCH ? nrel - idx : (uint32_t)MAX_MATCH;
+            mq[s] = 0;
+            hq[s] = !HAS_Q;
+            follow(s, w.link(idx));
+            if (st[s] == WALK) return;
+        }
+    };
+    MI355_UNROLL
+    for (int s = 0; s < U; s++) {
+        st[s] = IDLE;
+        retire(s);
+    }
+    for (uint32_t iter = 0;; iter++) {
+        bool walking = false, pending = false;
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            walking = walking || st[s] == WALK;
+            pending = pending || st[s] >= PARK;
+        }
+        if (!walking && !pending) break;
+        // The common step, branch free: link and probe of the current candidate are read together
+        // (for a slot that is not walking the reads are harmless and their results unused), then
+        // matching.rs:124-143 as selects.
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            rd[s] = w.link(cand[s]);
+            rv[s] = w.load32(cand[s] + best[s] - 1);
+        }
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            const bool walk = st[s] == WALK;
+            const bool hit = walk && (rv[s] & 0xffffu) == probe[s];   // :141-143, compare deferred
+            if (HAS_Q) {
+                const bool cap = walk && !hit && !hq[s] && it[s] == checks_q && it[s] < checks;
+                mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
+                hq[s] = hq[s] || cap;
+            }
+            const uint32_t c = cand[s] - rd[s];
+            const bool ok = it[s] < checks && rd[s] != 0 && rd[s] <= cand[s] && p[s] - c <= (uint32_t)WINDOW_SIZE;
+            const bool adv = walk && !hit && ok;
+            dsave[s] = hit ? rd[s] : dsave[s];
+            st[s] = walk ? (hit ? (uint32_t)PARK : (ok ? (uint32_t)WALK : (uint32_t)FIN)) : st[s];
+            cand[s] = adv ? c : cand[s];
+            it[s] += adv ? 1u : 0u;
+        }
+        walking = false;
+        pending = false;
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            walking = walking || st[s] == WALK;
+            pending = pending || st[s] >= PARK;
+        }
+        if (!policy(pending, walking, iter)) continue;
+        // ---- service: get_match_length (matching.rs:67-72) for the parked slots ----
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            ext[s] = st[s] == PARK;
+            len[s] = 0;
+        }
+        for (;;) {
+            bool any = false;
+            MI355_UNROLL
+            for (int s = 0; s < U; s++) any = any || ext[s];
+            if (!any) break;
+            MI355_UNROLL
+            for (int s = 0; s < U; s++)
+                if (ext[s]) {
+                    ra[s] = w.load32(p[s] + len[s]);
+                    rb[s] = w.load32(cand[s] + len[s]);
+                }
+            MI355_UNROLL
+            for (int s = 0; s < U; s++)
+                if (ext[s]) {
+                    uint32_t x = ra[s] ^ rb[s];
+                    if (x) {
+                        len[s] += ctz32(x) >> 3;
+                        ext[s] = false;
+                    } else {
+                        len[s] += 4;
+                    }
+                    if (len[s] >= maxlen[s]) {
+                        len[s] = maxlen[s];
+                        ext[s] = false;
+                    }
+                }
+        }
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            upd[s] = st[s] == PARK && len[s] > best[s];  // matching.rs:149-151
+            if (upd[s]) {
+                best[s] = len[s];
+                bestd[s] = p[s] - cand[s];
+                if (len[s] != maxlen[s]) rv[s] = w.load32(p[s] + best[s] - 1);
+            }
+        }
+        MI355_UNROLL
+        for (int s = 0; s < U; s++)
+            if (st[s] == PARK) {
+                if (upd[s] && len[s] == maxlen[s]) {
+                    st[s] = FIN;  // matching.rs:152-156
+                } else {
+                    if (upd[s]) probe[s] = rv[s] & 0xffffu;
+                    follow(s, dsave[s]);
+                }
+            }
+        // ---- service: finished slots report and take new positions ----
+        MI355_UNROLL
+        for (int s = 0; s < U; s++)
+            if (st[s] == FIN) retire(s);
+    }
+#undef MI355_UNROLL
+}
+
 // ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------
 // R[p] = number of bytes from p equal to data[p-1], capped at 258 and at the end of input; 0 if
 // p == 0 or data[p] != data[p-1].

@@ -37,6 +37,8 @@ struct MAcc {
     uint32_t operator()(uint64_t i) const { return m[i]; }
 };
 
+int g_multi = 0;  // use match_walk_multi (the k_match formulation) instead of match_walk
+
 struct Sim {
     std::vector<uint8_t> in;  // padded with 16 zero bytes
     uint64_t n;
@@ -72,6 +74,55 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
+    if (g_multi == 2) {
+        // the k_match formulation: parked extension, positions handed out by a shared counter
+        struct Emit {
+            Sim* s;
+            void operator()(uint32_t idx, uint32_t m, uint32_t mq) const {
+                s->M[idx] = m;
+                s->Mq[idx] = mq;
+            }
+        } emit{&s};
+        bool hasq = s.cfg.use_quarter && cq != 0;
+        const uint32_t T = 16384;
+        for (uint64_t E = 0; E < s.n; E += T) {
+            // one "lane" takes every position of the tile in turn (the hand-out order is free)
+            struct Next {
+                uint32_t cur, end;
+                uint32_t operator()() { return cur < end ? cur++ : (uint32_t)NO_POS; }
+            } next{(uint32_t)E, (uint32_t)(E + T)};
+            ServiceAlways pol;
+            if (hasq)
+                match_walk_park<4, true>(w, next, (uint32_t)s.n, s.cfg.checks, cq, emit, pol);
+            else
+                match_walk_park<4, false>(w, next, (uint32_t)s.n, s.cfg.checks, 0, emit, pol);
+        }
+        if (s.cfg.use_quarter && cq == 0)
+            for (uint64_t p = 0; p < s.n; p++) s.Mq[p] = 0;
+        return;
+    }
+    if (g_multi) {
+        // the k_match geometry: tiles of 16384 positions, 1024 lanes x 16 positions, 4 chains in flight
+        struct Emit {
+            Sim* s;
+            void operator()(uint32_t idx, uint32_t m, uint32_t mq) const {
+                s->M[idx] = m;
+                s->Mq[idx] = mq;
+            }
+        } emit{&s};
+        const uint32_t T = 16384, TH = 1024;
+        bool hasq = s.cfg.use_quarter && cq != 0;
+        for (uint64_t E = 0; E < s.n; E += T)
+            for (uint32_t tid = 0; tid < TH; tid++) {
+                if (hasq)
+                    match_walk_multi<4, true>(w, (uint32_t)(E + tid), TH, T / TH, (uint32_t)s.n, s.cfg.checks, cq, emit);
+                else
+                    match_walk_multi<4, false>(w, (uint32_t)(E + tid), TH, T / TH, (uint32_t)s.n, s.cfg.checks, 0, emit);
+            }
+        if (s.cfg.use_quarter && cq == 0)
+            for (uint64_t p = 0; p < s.n; p++) s.Mq[p] = 0;
+        return;
+    }
     for (uint64_t p = 0; p + 2 < s.n; p++) {
         uint32_t max_len = (uint32_t)std::min<uint64_t>(s.n - p, MAX_MATCH);
         uint32_t m, mq;
@@ -409,6 +460,8 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
     memcpy(out, o.data(), total_bytes);
     return 0;
 }
+
+void hostsim_use_multi(int on) { g_multi = on; }
 
 // expose M for diffing: longest_match(prev_length=0) for every position
 int hostsim_match_table(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t* m_out) {

@@ -48,6 +48,11 @@ def encode(data, checks, lazy_lt, matching_type, seg=0, fan=4):
     return rc, bytes(memoryview(out)[: olen.value]) if rc == 0 else b"", flags.value, bl
 
 
+def use_multi(on):
+    """switch the match stage to match_walk_multi (the formulation k_match runs)"""
+    lib().hostsim_use_multi(int(on))
+
+
 def match_table(data, checks):
     n = len(data)
     m = (C.c_uint32 * max(n, 1))()
