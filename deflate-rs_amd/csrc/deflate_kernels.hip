@@ -196,8 +196,23 @@ __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict
 // four hash chains in flight (match_walk_multi).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t MT = 16384;                               // positions per tile
-constexpr uint32_t MTHREADS = 1024;
-constexpr uint32_t MCHAINS = 4;                              // chains in flight per lane
+#ifndef MI355_MATCH_THREADS
+#define MI355_MATCH_THREADS 1024
+#endif
+constexpr uint32_t MTHREADS = MI355_MATCH_THREADS;
+#ifndef MI355_MATCH_U
+#define MI355_MATCH_U 2
+#endif
+#ifndef MI355_MATCH_R
+#define MI355_MATCH_R 8
+#endif
+#ifndef MI355_EXT_ROUNDS
+#define MI355_EXT_ROUNDS 100
+#endif
+#ifndef MI355_EXT_DENSE
+#define MI355_EXT_DENSE 1
+#endif
+constexpr uint32_t MCHAINS = MI355_MATCH_U;                  // chains in flight per lane
 constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // 49424, multiple of 16
 constexpr uint32_t MW_LINKS = WINDOW_SIZE + MT;
 
@@ -225,8 +240,14 @@ struct TileNext {
 // walk on (all lanes of a wave iterate in lockstep, so `iter` is uniform)
 struct WavePolicy {
     __device__ bool operator()(bool pending, bool walking, uint32_t iter) const {
-        if ((iter & 7) == 7) return true;
+        if ((iter % MI355_MATCH_R) == MI355_MATCH_R - 1) return true;
         return __ballot(walking) == 0;
+    }
+    // the compare loop is worth its instructions while many lanes take part; a few long matches go
+    // on at the next service instead of holding the whole wave
+    __device__ bool keep_extending(bool any, uint32_t round) const {
+        uint32_t cnt = (uint32_t)__popcll(__ballot(any));
+        return cnt >= MI355_EXT_DENSE || (round < MI355_EXT_ROUNDS && cnt > 0);
     }
 };
 
@@ -327,10 +348,20 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                              ParseCfg cfg, uint16_t* __restrict__ adv) {
-    uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    // four consecutive positions per lane: 16-byte loads of M, one 8-byte store of adv
+    uint64_t j0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= n) return;
     GM m{M}, mq{Mq ? Mq : M};
-    adv[j] = (uint16_t)parse_step(m, mq, j, (uint64_t)n, cfg).adv;
+    uint16_t a[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (j0 + q < n) a[q] = (uint16_t)parse_step(m, mq, j0 + q, (uint64_t)n, cfg).adv;
+    if (j0 + 4 <= n) {
+        uint2 v = make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
+        *reinterpret_cast<uint2*>(adv + j0) = v;  // adv is 256-byte aligned, j0 a multiple of 4
+    } else {
+        for (int q = 0; q < 4 && j0 + q < n; q++) adv[j0 + q] = a[q];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -911,25 +942,44 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
         put_bits(out32, bp, pl.bfinal ? 3u : 2u, 3);  // encoder_state.rs:10-11
     }
     bp += hdr_bits;
-    // tokens
+    // tokens: 4 consecutive tokens per lane and round; lengths are scanned inside the wave with
+    // shuffles and across the 4 waves through LDS (two barriers per 1024 tokens)
     const uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
     const uint64_t t1 = t0 + MAX_BUFFER_LENGTH < sc->T ? t0 + MAX_BUFFER_LENGTH : sc->T;
-    for (uint64_t tb = t0; tb < t1; tb += 256) {
-        uint64_t t = tb + tid;
-        uint32_t nbits = 0;
-        uint64_t bits = 0;
-        if (t < t1) bits = token_bits(dtok[t], s.llc, s.lll, s.dc, s.dl, &nbits);
-        s.scan[tid] = nbits;
-        __syncthreads();
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            uint32_t v = tid >= off ? s.scan[tid - off] : 0;
-            __syncthreads();
-            s.scan[tid] += v;
-            __syncthreads();
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    for (uint64_t tb = t0; tb < t1; tb += 1024) {
+        uint64_t tq = tb + 4ull * tid;
+        uint32_t nb4[4];
+        uint64_t bits4[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            nb4[q] = 0;
+            bits4[q] = 0;
+            if (tq + q < t1) bits4[q] = token_bits(dtok[tq + q], s.llc, s.lll, s.dc, s.dl, &nb4[q]);
+            mine += nb4[q];
         }
-        uint32_t incl = s.scan[tid];
-        uint32_t total = s.scan[255];
-        put_bits(out32, bp + (incl - nbits), bits, nbits);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += v;
+        }
+        if (lane == 63) s.scan[wv] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            uint32_t v = s.scan[k];
+            if (k < wv) wbase += v;
+            total += v;
+        }
+        uint64_t pos = bp + wbase + (incl - mine);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            put_bits(out32, pos, bits4[q], nb4[q]);
+            pos += nb4[q];
+        }
         bp += total;
         __syncthreads();
     }

@@ -264,8 +264,9 @@ MI355_HD void match_walk_multi(const W& w, uint32_t first, uint32_t stride, uint
 // Results are identical to match_walk, including tie-breaks.
 enum : uint32_t { NO_POS = 0xFFFFFFFFu };
 
-struct ServiceAlways {  // host policy: service parked / finished slots at once
+struct ServiceAlways {  // host policy: service parked / finished slots at once, extend to the end
     MI355_HD bool operator()(bool pending, bool /*walking*/, uint32_t /*iter*/) const { return pending; }
+    MI355_HD bool keep_extending(bool any, uint32_t /*round*/) const { return any; }
 };
 
 template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy>
@@ -354,9 +355,11 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
                 hq[s] = hq[s] || cap;
             }
             const uint32_t c = cand[s] - rd[s];
-            const bool ok = it[s] < checks && rd[s] != 0 && rd[s] <= cand[s] && p[s] - c <= (uint32_t)WINDOW_SIZE;
+            // (c may wrap below the window start; p - c is then still the true distance, > 32768)
+            const bool ok = it[s] < checks && rd[s] != 0 && p[s] - c <= (uint32_t)WINDOW_SIZE;
             const bool adv = walk && !hit && ok;
             dsave[s] = hit ? rd[s] : dsave[s];
+            len[s] = hit ? 0u : len[s];
             st[s] = walk ? (hit ? (uint32_t)PARK : (ok ? (uint32_t)WALK : (uint32_t)FIN)) : st[s];
             cand[s] = adv ? c : cand[s];
             it[s] += adv ? 1u : 0u;
@@ -370,16 +373,14 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
         }
         if (!policy(pending, walking, iter)) continue;
         // ---- service: get_match_length (matching.rs:67-72) for the parked slots ----
+        // (a slot whose compare is cut short by the policy stays parked and goes on next time)
         MI355_UNROLL
-        for (int s = 0; s < U; s++) {
-            ext[s] = st[s] == PARK;
-            len[s] = 0;
-        }
-        for (;;) {
+        for (int s = 0; s < U; s++) ext[s] = st[s] == PARK;
+        for (uint32_t round = 0;; round++) {
             bool any = false;
             MI355_UNROLL
             for (int s = 0; s < U; s++) any = any || ext[s];
-            if (!any) break;
+            if (!policy.keep_extending(any, round)) break;
             MI355_UNROLL
             for (int s = 0; s < U; s++)
                 if (ext[s]) {
@@ -404,7 +405,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
         }
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            upd[s] = st[s] == PARK && len[s] > best[s];  // matching.rs:149-151
+            upd[s] = st[s] == PARK && !ext[s] && len[s] > best[s];  // matching.rs:149-151
             if (upd[s]) {
                 best[s] = len[s];
                 bestd[s] = p[s] - cand[s];
@@ -413,7 +414,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
         }
         MI355_UNROLL
         for (int s = 0; s < U; s++)
-            if (st[s] == PARK) {
+            if (st[s] == PARK && !ext[s]) {
                 if (upd[s] && len[s] == maxlen[s]) {
                     st[s] = FIN;  // matching.rs:152-156
                 } else {

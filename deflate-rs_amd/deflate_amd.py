@@ -11,7 +11,7 @@ import enum
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355deflate.so")
+LIB_PATH = os.environ.get("MI355_DEFLATE_LIB", os.path.join(_HERE, "libmi355deflate.so"))
 
 FLUSH_FINISH, FLUSH_SYNC = 0, 1
 OK, E_ARG, E_OUT_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_REF_PANIC, E_STATE = 0, -1, -2, -3, -4, -5, -6

@@ -74,7 +74,7 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
-    if (g_multi == 2) {
+    if (g_multi >= 2) {
         // the k_match formulation: parked extension, positions handed out by a shared counter
         struct Emit {
             Sim* s;
@@ -91,6 +91,19 @@ void stage_match(Sim& s) {
                 uint32_t cur, end;
                 uint32_t operator()() { return cur < end ? cur++ : (uint32_t)NO_POS; }
             } next{(uint32_t)E, (uint32_t)(E + T)};
+            if (g_multi == 3) {
+                // service only every 3rd step and cut every compare after one round: exercises the
+                // "stay parked, go on next time" path the GPU policy takes for long matches
+                struct Cut {
+                    bool operator()(bool pending, bool walking, uint32_t iter) const { return pending && (iter % 3 == 2 || !walking); }
+                    bool keep_extending(bool any, uint32_t round) const { return any && round < 1; }
+                } pol;
+                if (hasq)
+                    match_walk_park<4, true>(w, next, (uint32_t)s.n, s.cfg.checks, cq, emit, pol);
+                else
+                    match_walk_park<4, false>(w, next, (uint32_t)s.n, s.cfg.checks, 0, emit, pol);
+                continue;
+            }
             ServiceAlways pol;
             if (hasq)
                 match_walk_park<4, true>(w, next, (uint32_t)s.n, s.cfg.checks, cq, emit, pol);

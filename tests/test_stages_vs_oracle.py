@@ -155,3 +155,24 @@ def test_q13_stored_after_slide_is_replicated():
         if hit >= 2:
             break
     assert hit >= 1
+
+
+# The three formulations of the chain walk in stages.h (single, multi-chain, parked) must give the
+# same match table and the same stream; mode 3 additionally cuts every compare short so that the
+# "stay parked, continue at the next service" path of the GPU policy is exercised.
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_match_walk_formulations_agree(mode):
+    cases = [datagen.text_like(200000, 3), datagen.mixed(150000, 5), datagen.rng_bytes(70000, 2), bytes(70000),
+             b"abcabcabcabc", (datagen.rng_bytes(300, 5) * 400)]
+    try:
+        for data in cases:
+            for checks in (1, 7, 128, 1768):
+                hs.use_multi(0)
+                a = hs.match_table(data, checks)
+                hs.use_multi(mode)
+                assert hs.match_table(data, checks) == a
+            hs.use_multi(mode)
+            for level in ("default", "best", "fast"):
+                agree(data, *LV[level])
+    finally:
+        hs.use_multi(0)
