@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random"])
     ap.add_argument("--size", type=int, default=0, help="bytes per GPU (0 = the config's size)")
+    ap.add_argument("--level", default="", choices=["", "default", "best", "fast", "rle", "huffman_only"],
+                    help="override the level of the workload (default: Default, rle() for zeros)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -63,8 +65,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     size = args.size or {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024}[args.workload]
-    options = da.CompressionOptions.rle() if args.workload == "zeros" else da.CompressionOptions.default()
-    level_name = "rle()" if args.workload == "zeros" else "Compression::Default"
+    lvl = args.level or ("rle" if args.workload == "zeros" else "default")
+    options = {"default": da.CompressionOptions.default, "best": da.CompressionOptions.high,
+               "fast": da.CompressionOptions.fast, "rle": da.CompressionOptions.rle,
+               "huffman_only": da.CompressionOptions.huffman_only}[lvl]()
+    level_name = {"default": "Compression::Default", "best": "Compression::Best", "fast": "Compression::Fast",
+                  "rle": "rle()", "huffman_only": "huffman_only()"}[lvl]
 
     data = make_input(args.workload, size, rank)
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
@@ -117,9 +123,16 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * size * args.steps / elapsed / 1e6
         mm = sum(match_ms) / len(match_ms)
-        dominant = "k_rle" if args.workload == "zeros" else "k_match"
+        dominant = "k_rle" if lvl == "rle" else "k_match"
         algo_bytes = size + out_len[0]  # 1 B read + r B written per input byte, one launch = one input
         achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0
+        traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            if pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and lvl == "default":
+                traffic = pm["kernels"]["k_match<false>"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "MB/s raw input encoded (Compression::Default) + compressed size vs ref",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -132,15 +145,16 @@ def main():
             "gpu_ms_per_step_events": round(sum(gpu_ms) / len(gpu_ms), 3),
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
-            lvl = ob.RLE if args.workload == "zeros" else ob.DEFAULT
-            sample = data if args.workload != "zeros" else data
+            olvl = {"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST, "rle": ob.RLE,
+                    "huffman_only": ob.HUFFMAN_ONLY}[lvl]
+            sample = data
             t1 = time.perf_counter()
-            ref = ob.encode(sample, level=lvl)
+            ref = ob.encode(sample, level=olvl)
             dt = time.perf_counter() - t1
             got = bytes(d_out[: out_len[0]].cpu().numpy())
             res["cpu_baseline"] = {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",

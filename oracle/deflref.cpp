@@ -1540,7 +1540,7 @@ void deflref_preset(int level, deflref_opts* out) {
     *out = o;
 }
 
-size_t deflref_bound(size_t in_len) { return in_len + 5 * (in_len / 32767 + 2) + 64; }
+size_t deflref_bound(size_t in_len) { return in_len + 5 * (in_len / 31744 + in_len / 32767 + 2) + 64; }
 
 const char* deflref_last_panic(void) { return g_last_panic.c_str(); }
 int deflref_last_hazards(void) { return g_hazards; }
