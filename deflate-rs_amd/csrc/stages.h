@@ -274,7 +274,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
                               const Policy& policy) {
     enum : uint32_t { IDLE = 0, WALK = 1, PARK = 2, FIN = 3 };
     uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], st[U], dsave[U], len[U], mq[U];
-    uint32_t rd[U], rv[U], ra[U], rb[U];
+    uint32_t rd[U], rv[U], ra[U], rb[U], ra2[U], rb2[U];
     bool hq[U], ext[U], upd[U];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MI355_UNROLL _Pragma("unroll")
@@ -381,21 +381,27 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
             MI355_UNROLL
             for (int s = 0; s < U; s++) any = any || ext[s];
             if (!policy.keep_extending(any, round)) break;
+            // eight bytes per round trip: most matches on text end inside the first round
             MI355_UNROLL
             for (int s = 0; s < U; s++)
                 if (ext[s]) {
                     ra[s] = w.load32(p[s] + len[s]);
                     rb[s] = w.load32(cand[s] + len[s]);
+                    ra2[s] = w.load32(p[s] + len[s] + 4);
+                    rb2[s] = w.load32(cand[s] + len[s] + 4);
                 }
             MI355_UNROLL
             for (int s = 0; s < U; s++)
                 if (ext[s]) {
-                    uint32_t x = ra[s] ^ rb[s];
+                    uint32_t x = ra[s] ^ rb[s], y = ra2[s] ^ rb2[s];
                     if (x) {
                         len[s] += ctz32(x) >> 3;
                         ext[s] = false;
+                    } else if (y) {
+                        len[s] += 4 + (ctz32(y) >> 3);
+                        ext[s] = false;
                     } else {
-                        len[s] += 4;
+                        len[s] += 8;
                     }
                     if (len[s] >= maxlen[s]) {
                         len[s] = maxlen[s];
