@@ -38,7 +38,13 @@ struct LdsWin {  // the window of k_match: bytes and links in one window coordin
         uint32_t lo = w[0], hi = w[1];
         return __builtin_amdgcn_alignbyte(hi, lo, i & 3);
     }
-    __device__ uint32_t link(uint32_t i) const { return lk[i]; }
+    // the window keeps "no earlier position" as 0xFFFF (k_match converts while staging), so the
+    // common step needs no separate test for it
+    __device__ uint32_t link_far(uint32_t i) const { return lk[i]; }
+    __device__ uint32_t link(uint32_t i) const {
+        uint32_t d = lk[i];
+        return d == 0xFFFFu ? 0u : d;
+    }
 };
 
 // Lanes of ONE wave handing data to each other through LDS: the hardware executes a wave's LDS
@@ -297,7 +303,14 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
                 if (g + b < n) t[b >> 1] |= (uint32_t)link[g + b] << (16 * (b & 1));
             v = make_uint4(t[0], t[1], t[2], t[3]);
         }
-        reinterpret_cast<uint4*>(s_link)[w] = v;
+        // 0 (none) -> 0xFFFF per halfword
+        uint32_t t4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t lo = t4[q] & 0xffffu, hi = t4[q] >> 16;
+            t4[q] = (lo ? lo : 0xffffu) | ((hi ? hi : 0xffffu) << 16);
+        }
+        reinterpret_cast<uint4*>(s_link)[w] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
     }
     if (tid == 0) s_next = 0;
     __syncthreads();

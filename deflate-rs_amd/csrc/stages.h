@@ -289,9 +289,9 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
             mq[s] = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
             hq[s] = true;
         }
-        if (d == 0 || d > cand[s]) return;
+        if (d == 0) return;
         uint32_t c = cand[s] - d;
-        if (p[s] - c > WINDOW_SIZE) return;
+        if (p[s] - c > WINDOW_SIZE) return;  // also catches d == 0xFFFF ("none" of link_far)
         cand[s] = c;
         it[s]++;
         st[s] = WALK;
@@ -320,6 +320,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
             maxlen[s] = nrel - idx < (uint32_t)MAX_MATCH ? nrel - idx : (uint32_t)MAX_MATCH;
             mq[s] = 0;
             hq[s] = !HAS_Q;
+            len[s] = 0;
             follow(s, w.link(idx));
             if (st[s] == WALK) return;
         }
@@ -342,7 +343,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
         // matching.rs:124-143 as selects.
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            rd[s] = w.link(cand[s]);
+            rd[s] = w.link_far(cand[s]);  // 0xFFFF = no earlier position: fails the distance test below
             rv[s] = w.load32(cand[s] + best[s] - 1);
         }
         MI355_UNROLL
@@ -356,10 +357,9 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
             }
             const uint32_t c = cand[s] - rd[s];
             // (c may wrap below the window start; p - c is then still the true distance, > 32768)
-            const bool ok = it[s] < checks && rd[s] != 0 && p[s] - c <= (uint32_t)WINDOW_SIZE;
+            const bool ok = it[s] < checks && p[s] - c <= (uint32_t)WINDOW_SIZE;
             const bool adv = walk && !hit && ok;
             dsave[s] = hit ? rd[s] : dsave[s];
-            len[s] = hit ? 0u : len[s];
             st[s] = walk ? (hit ? (uint32_t)PARK : (ok ? (uint32_t)WALK : (uint32_t)FIN)) : st[s];
             cand[s] = adv ? c : cand[s];
             it[s] += adv ? 1u : 0u;
@@ -427,6 +427,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
                     if (upd[s]) probe[s] = rv[s] & 0xffffu;
                     follow(s, dsave[s]);
                 }
+                len[s] = 0;  // the next compare of this slot starts from byte 0 again
             }
         // ---- service: finished slots report and take new positions ----
         MI355_UNROLL

@@ -30,6 +30,7 @@ struct HostWin {  // absolute index space
         return v;
     }
     uint32_t link(uint32_t i) const { return lk[i]; }
+    uint32_t link_far(uint32_t i) const { return lk[i] ? lk[i] : 0xFFFFu; }
 };
 
 struct MAcc {
