@@ -472,11 +472,13 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
 // One wave per segment: lane 0 follows adv[] from the segment's entry (the chain itself is serial,
 // but it now runs on LDS latency), then all lanes expand the path positions into tokens in parallel
 // and a wave scan places them.
+// (Segments are relative to pos0: the sharded path parses a sub-range [pos0, pos0 + n) of a buffer of
+// n_total bytes; the whole-buffer path has pos0 = 0, n = n_total.)
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                               const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
                                               const uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
-                                              uint32_t* __restrict__ cnt) {
+                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total) {
     __shared__ uint16_t s_adv[4][SEG];
     __shared__ uint16_t s_pp[4][SEG];
     __shared__ uint32_t s_np[4];
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
     const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
     const uint32_t len = (uint32_t)(b - a);
-    for (uint32_t r = lane; r < len; r += 64) s_adv[wv][r] = adv[a + r];
+    for (uint32_t r = lane; r < len; r += 64) s_adv[wv][r] = adv[(uint64_t)pos0 + a + r];
     wave_lds_fence();
     if (lane == 0) {
         uint32_t np = 0;
@@ -512,8 +514,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         st.adv = 0;
         uint64_t j = 0;
         if (have) {
-            j = a + s_pp[wv][idx];
-            st = parse_step(m, mq, j, (uint64_t)n, cfg);
+            j = (uint64_t)pos0 + a + s_pp[wv][idx];
+            st = parse_step(m, mq, j, (uint64_t)n_total, cfg);
         }
         uint32_t ntok = st.nlit + (st.mlen ? 1u : 0u);
         uint32_t incl = ntok;
@@ -1000,6 +1002,93 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sharded (multi-GPU, stream-exact) path: the blocks a rank owns are cut out of its own tokens plus
+// the tokens its right neighbour sent, so block geometry comes from token covers alone.
+// k_cover: per block the bytes its tokens cover and its last token; slot 0 = the `skip` tokens that
+// belong to the left neighbour's last block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cover(const uint32_t* __restrict__ dtok, uint64_t skip, uint64_t T2,
+                                               uint32_t nb2, uint64_t* __restrict__ cover,
+                                               uint32_t* __restrict__ last_tok) {
+    __shared__ uint64_t red[256];
+    const uint32_t slot = blockIdx.x;  // 0 = head, 1 + b = block b
+    if (slot > nb2) return;
+    uint64_t t0, t1;
+    if (slot == 0) {
+        t0 = 0;
+        t1 = skip;
+    } else {
+        t0 = skip + (uint64_t)(slot - 1) * MAX_BUFFER_LENGTH;
+        t1 = t0 + MAX_BUFFER_LENGTH < skip + T2 ? t0 + MAX_BUFFER_LENGTH : skip + T2;
+    }
+    uint64_t s = 0;
+    for (uint64_t t = t0 + threadIdx.x; t < t1; t += 256) s += tok_cover(dtok[t]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 128; off; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cover[slot] = red[0];
+        if (slot) last_tok[slot - 1] = t1 > t0 ? dtok[t1 - 1] : 0u;
+    }
+}
+
+// block start positions (buffer coordinates) and the Q13 condition (global window geometry)
+__global__ void k_shard_bounds(uint64_t first_pos, const uint64_t* __restrict__ cover,
+                               const uint32_t* __restrict__ last_tok, uint32_t nb2, uint64_t T2, uint32_t mode,
+                               uint64_t global_lo, uint64_t n_global, uint32_t* __restrict__ bstart,
+                               uint32_t* __restrict__ q13) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t pos = first_pos + cover[0];
+    for (uint32_t b = 0; b < nb2; b++) {
+        bstart[b] = (uint32_t)pos;
+        uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
+        uint32_t flag = 0;
+        if (t0 + MAX_BUFFER_LENGTH <= T2) {
+            uint32_t tk = last_tok[b];
+            if (tk >> 16) {
+                uint64_t mend = global_lo + pos + cover[1 + b];  // absolute end of the last token
+                uint64_t tp = mend - tok_cover(tk);
+                uint64_t lp = (mode == MODE_LAZY) ? tp + 1 : tp;
+                uint64_t wdx = lp / WINDOW_SIZE;
+                uint64_t wend = (wdx + 1) * (uint64_t)WINDOW_SIZE;
+                if (wdx >= 1 && mend > wend) {
+                    uint64_t buf_end = wdx * (uint64_t)WINDOW_SIZE + 65794;
+                    if (buf_end > n_global) buf_end = n_global;
+                    flag = (mend + WINDOW_SIZE > buf_end) ? 2u : 1u;
+                }
+            }
+        }
+        q13[b] = flag;
+        pos += cover[1 + b];
+    }
+    bstart[nb2] = (uint32_t)pos;
+}
+
+struct ShardCost {  // what the global, serial plan needs from each block
+    uint64_t dyn_bits, dyn_est, static_est, fixed_bits, in_bytes;
+    uint32_t q13, pad;
+};
+__global__ __launch_bounds__(256) void k_shard_costs(const BlockHeader* __restrict__ hdr,
+                                                     const uint32_t* __restrict__ bstart,
+                                                     const uint32_t* __restrict__ q13, uint32_t nb2,
+                                                     ShardCost* __restrict__ out) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb2) return;
+    ShardCost c;
+    c.dyn_bits = hdr[b].dyn_bits;
+    c.dyn_est = hdr[b].dyn_est;
+    c.static_est = hdr[b].static_est;
+    c.fixed_bits = hdr[b].fixed_bits;
+    c.in_bytes = (uint64_t)bstart[b + 1] - bstart[b];
+    c.q13 = q13[b];
+    c.pad = 0;
+    out[b] = c;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adler-32 (RFC 1950; crate adler32 as used by checksum.rs:33-57): per-chunk (a, b) partials,
 // then one lane folds them: a' = a + a_c, b' = b + len_c * a + b_c (mod 65521).
 // ---------------------------------------------------------------------------------------------
@@ -1061,3 +1150,4 @@ __global__ void k_zlib_frame(DevScalars* sc, uint8_t* out, uint32_t trailer) {
 }  // namespace mi355
 
 #include "deflate_host.inc"
+#include "deflate_shard.inc"

@@ -39,6 +39,11 @@ class BlockInfo(C.Structure):
                 ("in_bytes", C.c_uint64), ("bit_start", C.c_uint64)]
 
 
+class BlockCost(C.Structure):
+    _fields_ = [("dyn_bits", C.c_uint64), ("dyn_est", C.c_uint64), ("static_est", C.c_uint64),
+                ("fixed_bits", C.c_uint64), ("in_bytes", C.c_uint64), ("q13", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class MatchingType(enum.IntEnum):
     """src/lz77.rs:27-37"""
     Greedy = 0
@@ -127,6 +132,18 @@ def load():
                                               C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     L.mi355_deflate_last_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.mi355_deflate_last_blocks.argtypes = [C.c_void_p, C.POINTER(BlockInfo), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64,
+                                    C.c_uint64, C.POINTER(Opts), C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mi355_shard_exit_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mi355_shard_emit.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+    L.mi355_shard_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(BlockCost), C.c_size_t]
+    L.mi355_plan_blocks.argtypes = [C.POINTER(BlockCost), C.c_size_t, C.c_uint32, C.POINTER(BlockInfo),
+                                    C.POINTER(C.c_uint64)]
+    L.mi355_shard_pack.argtypes = [C.c_void_p, C.POINTER(BlockInfo), C.c_uint64, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    L.mi355_shard_end.argtypes = [C.c_void_p]
+    L.mi355_shard_end.restype = None
     L.mi355_adler32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
     L.mi355_deflate_stream_new.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
     L.mi355_deflate_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -145,6 +162,8 @@ EXPORTED = [
     "mi355_deflate_encode_device", "mi355_deflate_last_info", "mi355_deflate_last_blocks", "mi355_adler32_device",
     "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_finish",
     "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
+    "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
+    "mi355_shard_pack", "mi355_shard_end",
 ]
 
 
@@ -324,3 +343,95 @@ class ZlibEncoder(_Encoder):
         if rc != OK:
             raise DeflateError(rc, "stream_checksum")
         return a.value
+
+
+# ---- sharded, stream-exact encode: the per-rank phases (mi355_shard_*) -------------------------------
+ZONE = 576
+BLOCK_TOKENS = 31744
+
+
+class Shard:
+    """One rank's session of the sharded (P1) encode; see include/mi355_deflate.h."""
+
+    def __init__(self, ctx, d_ext_ptr, n_ext, parse_lo, parse_hi, global_lo, n_global, options=Compression.Default,
+                 compat=0, stream=0):
+        self.ctx = ctx
+        o = CompressionOptions.from_(options).to_c(0, compat, 0)
+        h = C.c_void_p()
+        rc = load().mi355_shard_begin(ctx._h, C.c_void_p(d_ext_ptr), n_ext, parse_lo, parse_hi, global_lo, n_global,
+                                      C.byref(o), C.c_void_p(stream), C.byref(h))
+        if rc != OK:
+            ctx._err(rc)
+        self._h = h
+        self.compat = compat
+        self.nb = 0
+
+    def exit_table(self):
+        t = (C.c_uint32 * ZONE)()
+        rc = load().mi355_shard_exit_table(self._h, t)
+        if rc != OK:
+            self.ctx._err(rc)
+        return list(t)
+
+    def emit(self, entry):
+        """-> (token count, device pointer of the dense token array)"""
+        n = C.c_uint64(0)
+        p = C.c_void_p()
+        rc = load().mi355_shard_emit(self._h, entry, C.byref(n), C.byref(p))
+        if rc != OK:
+            self.ctx._err(rc)
+        return n.value, (p.value or 0)
+
+    def blocks(self, skip, d_tail_ptr, n_tail):
+        """-> list of cost tuples (dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, q13)"""
+        nb = C.c_uint64(0)
+        cap = 1 << 16
+        costs = (BlockCost * cap)()
+        rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, cap)
+        if rc != OK:
+            self.ctx._err(rc)
+        if nb.value > cap:
+            costs = (BlockCost * nb.value)()
+            rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, nb.value)
+            if rc != OK:
+                self.ctx._err(rc)
+        self.nb = nb.value
+        return [(c.dyn_bits, c.dyn_est, c.static_est, c.fixed_bits, c.in_bytes, c.q13) for c in costs[: nb.value]]
+
+    def pack(self, plans, end_bit, d_out_ptr, out_cap):
+        """plans: list of (btype, bfinal, bit_start) of this rank's blocks -> (first_byte, n_bytes)"""
+        arr = (BlockInfo * max(1, len(plans)))()
+        for i, (bt, bf, bs) in enumerate(plans):
+            arr[i].btype, arr[i].bfinal, arr[i].bit_start = bt, bf, bs
+        fb = C.c_uint64(0)
+        nbts = C.c_size_t(0)
+        rc = load().mi355_shard_pack(self._h, arr, end_bit, C.c_void_p(d_out_ptr), out_cap, C.byref(fb), C.byref(nbts))
+        if rc != OK:
+            self.ctx._err(rc)
+        return fb.value, nbts.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mi355_shard_end(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_blocks(costs, compat=0):
+    """The serial block plan over the costs of ALL blocks of the stream (host; identical on every rank).
+    -> (list of (btype, bfinal, bit_start), total_bits)"""
+    n = len(costs)
+    arr = (BlockCost * max(1, n))()
+    for i, c in enumerate(costs):
+        (arr[i].dyn_bits, arr[i].dyn_est, arr[i].static_est, arr[i].fixed_bits, arr[i].in_bytes, arr[i].q13) = c
+    out = (BlockInfo * max(1, n))()
+    tot = C.c_uint64(0)
+    rc = load().mi355_plan_blocks(arr, n, compat, out, C.byref(tot))
+    if rc != OK:
+        raise DeflateError(rc, "mi355_plan_blocks")
+    return [(o.btype, o.bfinal, o.bit_start) for o in out[:n]], tot.value

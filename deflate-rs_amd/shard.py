@@ -55,3 +55,190 @@ def stitch(local_out, local_len, rank, world, group=None):
     if local_len:
         dist.send(local_out[:local_len].contiguous(), dst=0, group=group)
     return None, total
+
+
+# =====================================================================================================
+# Stream-exact (P1) sharding: the stitched stream equals the reference run on the WHOLE input.
+# include/mi355_deflate.h ("sharded encode") describes the per-rank phases; here is what travels
+# between them.  All of it is tiny next to the data: 576 x 4 bytes of exit table, 8 bytes of token
+# count, at most 31743 x 4 bytes of straddling tokens and 48 bytes per block of costs per rank.
+# =====================================================================================================
+HISTORY = 32768          # bytes of history in front of a rank's range (the match window)
+LOOKAHEAD = 66 * 1024    # bytes behind it: 258 of match look-ahead + room for a stored straddling block
+BLOCK_TOKENS = 31744
+ZONE = 576
+
+
+def p1_layout(total, rank, world):
+    """-> dict(a, b: the rank's byte range; g_lo, g_hi: the bytes it must hold; lo, hi: a, b in buffer
+    coordinates)."""
+    a, b = shard_range(total, rank, world)
+    g_lo = max(0, a - HISTORY)
+    g_hi = min(total, b + LOOKAHEAD)
+    return dict(a=a, b=b, g_lo=g_lo, g_hi=g_hi, lo=a - g_lo, hi=b - g_lo)
+
+
+def p1_entries(layouts, tables):
+    """Entry position (global) of every rank from the exit tables: E_0 = 0, E_{r+1} = where the parse
+    that enters rank r at E_r leaves it."""
+    entries = []
+    e = 0
+    for L, X in zip(layouts, tables):
+        entries.append(e)
+        if e < L["b"]:
+            off = e - L["a"]
+            assert 0 <= off < ZONE, "entry outside the entry zone"
+            e = L["b"] + X[off]
+    return entries
+
+
+def p1_token_split(counts):
+    """From the token counts: for every rank (skip, tail) = how many of its first tokens belong to the
+    left neighbour's last block, and how many tokens it needs from the right neighbour."""
+    world = len(counts)
+    first = [0] * world
+    for r in range(1, world):
+        first[r] = first[r - 1] + counts[r - 1]
+    skip = [(-first[r]) % BLOCK_TOKENS if r else 0 for r in range(world)]
+    for r in range(world):
+        if skip[r] > counts[r]:
+            raise ValueError("rank %d holds fewer tokens than one block boundary needs; use fewer ranks" % r)
+    tail = [skip[r + 1] if r + 1 < world else 0 for r in range(world)]
+    return skip, tail
+
+
+def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
+    """All ranks in ONE process (one context per virtual rank, any devices): the same phases and the same
+    exchanges as the distributed driver, with Python lists as the network.  Used by the GPU tests on a
+    single-GPU box.  Returns the stitched stream (bytes)."""
+    import torch
+    options = options if options is not None else da.Compression.Default
+    world = len(ctxs)
+    total = len(data)
+    lay = [p1_layout(total, r, world) for r in range(world)]
+    bufs, shards = [], []
+    for r in range(world):
+        L = lay[r]
+        t = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).to(
+            "cuda:%d" % ctxs[r].device)
+        bufs.append(t)
+        shards.append(da.Shard(ctxs[r], t.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total,
+                               options, compat))
+    tables = [s.exit_table() for s in shards]                                  # exchange 1
+    entries = p1_entries(lay, tables)
+    toks = [shards[r].emit(entries[r] - lay[r]["g_lo"]) for r in range(world)]  # (count, dptr)
+    counts = [c for c, _ in toks]                                              # exchange 2
+    skip, tail = p1_token_split(counts)
+    costs = []
+    for r in range(world):                                                     # exchange 3: straddling tokens
+        tail_ptr = toks[r + 1][1] if tail[r] else 0
+        costs.append(shards[r].blocks(skip[r], tail_ptr, tail[r]))
+    allc = [c for cs in costs for c in cs]                                     # exchange 4
+    plans, total_bits = da.plan_blocks(allc, compat)
+    out = torch.zeros((total_bits + 7) // 8 + 16, dtype=torch.uint8)
+    b0 = 0
+    for r in range(world):
+        nb = len(costs[r])
+        mine = plans[b0:b0 + nb]
+        end_bit = plans[b0 + nb][2] if b0 + nb < len(plans) else total_bits
+        b0 += nb
+        if not nb:
+            continue
+        cap = (end_bit - mine[0][2]) // 8 + 64
+        dev = torch.empty(cap, dtype=torch.uint8, device=bufs[r].device)
+        fb, nbytes = shards[r].pack(mine, end_bit, dev.data_ptr(), cap)
+        out[fb:fb + nbytes] |= dev[:nbytes].cpu()                             # exchange 5: OR-stitch
+    for s in shards:
+        s.close()
+    return bytes(out[: (total_bits + 7) // 8].numpy())
+
+
+def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, compat=0, group=None):
+    """One rank of the distributed driver.  d_ext: uint8 device tensor holding bytes [g_lo, g_hi) of the
+    input (+ >= 16 bytes of slack).  Returns (tensor on rank 0 | None, stream length in bytes)."""
+    import torch
+    options = options if options is not None else da.Compression.Default
+    dev = d_ext.device
+    L = layout
+    sh = da.Shard(ctx, d_ext.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total, options, compat,
+                  torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0)
+    # exchange 1: exit tables
+    mine = torch.tensor(sh.exit_table(), dtype=torch.int64, device=dev)
+    allt = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allt, mine, group=group)
+    lays = [p1_layout(total, r, world) for r in range(world)]
+    entries = p1_entries(lays, [t.tolist() for t in allt])
+    n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
+    # exchange 2: token counts
+    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(cnt, torch.tensor([n_tok], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in cnt]
+    skip, tail = p1_token_split(counts)
+    # exchange 3: the head tokens of rank r+1 complete the last block of rank r
+    import ctypes
+    reqs = []
+    head = None
+    if rank > 0 and skip[rank]:
+        head = torch.empty(skip[rank], dtype=torch.int32, device=dev)
+        ctypes_copy_d2d(head.data_ptr(), tok_ptr, skip[rank] * 4)
+        reqs.append(dist.isend(head, dst=rank - 1, group=group))
+    tail_t = None
+    if tail[rank]:
+        tail_t = torch.empty(tail[rank], dtype=torch.int32, device=dev)
+        dist.recv(tail_t, src=rank + 1, group=group)
+    for q in reqs:
+        q.wait()
+    costs = sh.blocks(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
+    # exchange 4: block costs (6 x int64 per block), padded to the largest rank
+    nbs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(nbs, torch.tensor([len(costs)], dtype=torch.int64, device=dev), group=group)
+    nbs = [int(x.item()) for x in nbs]
+    mx = max(1, max(nbs))
+    flat = torch.zeros(mx * 6, dtype=torch.int64, device=dev)
+    if costs:
+        flat[: len(costs) * 6] = torch.tensor([v for c in costs for v in c], dtype=torch.int64, device=dev)
+    allc_t = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(allc_t, flat, group=group)
+    allc = []
+    for r in range(world):
+        v = allc_t[r][: nbs[r] * 6].tolist()
+        allc.extend(tuple(v[i * 6:(i + 1) * 6]) for i in range(nbs[r]))
+    plans, total_bits = da.plan_blocks(allc, compat)
+    b0 = sum(nbs[:rank])
+    mine_p = plans[b0:b0 + nbs[rank]]
+    end_bit = plans[b0 + nbs[rank]][2] if b0 + nbs[rank] < len(plans) else total_bits
+    fb, nbytes = 0, 0
+    dev_out = None
+    if mine_p:
+        cap = (end_bit - mine_p[0][2]) // 8 + 64
+        dev_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        fb, nbytes = sh.pack(mine_p, end_bit, dev_out.data_ptr(), cap)
+    sh.close()
+    # exchange 5: byte ranges to rank 0, OR-ed (neighbours share the seam word)
+    meta = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(meta, torch.tensor([fb, nbytes], dtype=torch.int64, device=dev), group=group)
+    meta = [(int(m[0].item()), int(m[1].item())) for m in meta]
+    stream_len = (total_bits + 7) // 8
+    if rank == 0:
+        out = torch.zeros(stream_len + 16, dtype=torch.uint8, device=dev)
+        if nbytes:
+            out[fb:fb + nbytes] |= dev_out[:nbytes]
+        for r in range(1, world):
+            f, k = meta[r]
+            if k:
+                tmp = torch.empty(k, dtype=torch.uint8, device=dev)
+                dist.recv(tmp, src=r, group=group)
+                out[f:f + k] |= tmp
+        return out[:stream_len], stream_len
+    if nbytes:
+        dist.send(dev_out[:nbytes].contiguous(), dst=0, group=group)
+    return None, stream_len
+
+
+def ctypes_copy_d2d(dst_ptr, src_ptr, nbytes):
+    """device-to-device copy of raw pointers (the token array lives in the library's workspace)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    rc = hip.hipMemcpy(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3)
+    if rc != 0:
+        raise RuntimeError("hipMemcpy D2D failed: %d" % rc)

@@ -139,6 +139,40 @@ typedef struct {
 } mi355_block_info;
 int mi355_deflate_last_blocks(mi355_deflate_ctx* ctx, mi355_block_info* out, size_t cap, size_t* n_blocks);
 
+/* ---- sharded encode: ONE input over several GPUs, stream-exact (P1) ---------------------------
+ * Rank r holds in device memory the bytes [global_lo, global_lo + n_ext) of the input: its own range
+ * [parse_lo, parse_hi) (buffer coordinates; parse_lo = 32768 of history except on the first rank,
+ * global_lo a multiple of 32768) plus >= 66 KiB of look-ahead except on the last rank.  What the
+ * reference's single loop threads through the stream (src/lz77.rs parse state, the 31744-value block
+ * counter src/output_writer.rs:19, the bit position src/compress.rs:167) is exchanged between the
+ * phases: a 576-entry exit table, token counts, <= 31743 straddling tokens, per-block costs.
+ *   1. begin      links, match table, restart steps, exit table of [parse_lo, parse_hi)
+ *   2. exit_table X[e] = where the parse leaves the range (offset beyond parse_hi) if it enters at
+ *                 parse_lo + e;  all-gather, then every rank knows its entry position
+ *   3. emit       tokens of the path positions in [entry, parse_hi); all-gather the counts;
+ *                 rank r sends the first (-first_token_index mod 31744) of its tokens to rank r-1
+ *   4. blocks     histogram + Huffman per owned block -> cost records; all-gather
+ *   5. mi355_plan_blocks (host, every rank, identical result) -> block types and global bit offsets
+ *   6. pack       the rank's blocks at their global bit offsets; byte ranges are OR-stitched on rank 0
+ * deflate-rs_amd/shard.py drives this over torch.distributed. */
+typedef struct mi355_shard mi355_shard;
+typedef struct {
+    uint64_t dyn_bits, dyn_est, static_est, fixed_bits, in_bytes;
+    uint32_t q13, reserved;
+} mi355_block_cost;
+int mi355_shard_begin(mi355_deflate_ctx* ctx, const void* d_ext, size_t n_ext, size_t parse_lo, size_t parse_hi,
+                      uint64_t global_lo, uint64_t n_global, const mi355_deflate_opts* opts, void* hip_stream,
+                      mi355_shard** out);
+int mi355_shard_exit_table(mi355_shard* s, uint32_t* table576);
+int mi355_shard_emit(mi355_shard* s, uint64_t entry, uint64_t* n_tokens, const void** d_tokens);
+int mi355_shard_blocks(mi355_shard* s, uint64_t skip_tokens, const void* d_tail_tokens, uint64_t n_tail,
+                       uint64_t* n_blocks, mi355_block_cost* costs, size_t costs_cap);
+int mi355_plan_blocks(const mi355_block_cost* costs, size_t n, uint32_t compat, mi355_block_info* plans,
+                      uint64_t* total_bits);
+int mi355_shard_pack(mi355_shard* s, const mi355_block_info* plans, uint64_t end_bit, void* d_out, size_t out_cap,
+                     uint64_t* first_byte, size_t* n_bytes);
+void mi355_shard_end(mi355_shard* s);
+
 /* Adler-32 of a device buffer (crate adler32's RollingAdler32::update_buffer as used by
  * src/checksum.rs:33-57), computed on the GPU. */
 int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, uint32_t* adler, void* hip_stream);

@@ -286,3 +286,28 @@ def test_sync_flush_chunks_and_stitch(da, ctx):
     s.write_all(data[:50000])
     s.flush()
     assert z == s.output()
+
+
+# Stream-exact (P1) sharding: several virtual ranks on this one GPU run the sharded phases and exchange
+# exit tables / token counts / straddling tokens / block costs exactly as the distributed driver does;
+# the stitched stream must equal the oracle's stream for the WHOLE input, byte for byte.
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_p1_sharded_stream_exact(da, world):
+    import shard
+    ctxs = [da.Context(0) for _ in range(world)]
+    try:
+        cases = [("text", datagen.text_like(3_000_000, 31), "default"),
+                 ("mixed", datagen.mixed(2_500_000, 8), "default"),
+                 ("random", datagen.rng_bytes(1_200_000, 9), "default"),   # stored blocks, Q1 on rank 0
+                 ("zeros", bytes(40_000_000), "default"),                 # never-merging 258-byte steps
+                 ("text-fast", datagen.text_like(2_000_000, 32), "fast"),
+                 ("text-rle", datagen.text_like(1_500_000, 33), "rle")]
+        for name, data, level in cases:
+            c, l, m = LV[level]
+            ref = ob.encode(data, opts=ob.make_opts(c, l, m))
+            got = shard.encode_p1_virtual(da, ctxs, data, da.CompressionOptions(c, l, m), compat=1)
+            assert got == ref, "%s/%s world=%d: sharded stream differs (%d vs %d bytes)" % (
+                name, level, world, len(got), len(ref))
+    finally:
+        for c in ctxs:
+            c.close()

@@ -74,3 +74,28 @@ def test_shard_ranges_cover_input():
             rs = [shard.shard_range(total, r, world) for r in range(world)]
             assert rs[0][0] == 0 and rs[-1][1] == total
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+def test_p1_exchange_math():
+    import shard
+    # token split: every non-final rank ends on a block boundary after the exchange
+    counts = [100000, 70000, 31744, 5]
+    skip, tail = shard.p1_token_split(counts)
+    first = [0, 100000, 170000, 201744]
+    for r in range(4):
+        assert (first[r] + skip[r]) % shard.BLOCK_TOKENS == 0
+        owned = counts[r] - skip[r] + tail[r]
+        if r < 3:
+            assert owned % shard.BLOCK_TOKENS == 0
+    assert tail[:3] == skip[1:]
+    # entries: a rank whose range is jumped over keeps the incoming position
+    lays = [dict(a=0, b=1000), dict(a=1000, b=1200), dict(a=1200, b=3000)]
+    tabs = [[300] * shard.ZONE, [7] * shard.ZONE, [0] * shard.ZONE]
+    assert shard.p1_entries(lays, tabs) == [0, 1300, 1300]
+    # layouts cover the input with history and look-ahead clipped to it
+    for total in (100, 5_000_000):
+        for world in (1, 3):
+            ls = [shard.p1_layout(total, r, world) for r in range(world)]
+            assert ls[0]["g_lo"] == 0 and ls[-1]["g_hi"] == total
+            for L in ls:
+                assert L["g_lo"] % 32768 == 0 and L["lo"] % 1024 == 0
