@@ -79,22 +79,25 @@ def test_shard_ranges_cover_input():
 def test_p1_exchange_math():
     import shard
     # token split: every non-final rank ends on a block boundary after the exchange
-    counts = [100000, 70000, 31744, 5]
+    counts = [100000, 70000, 40000, 50000]
     skip, tail = shard.p1_token_split(counts)
-    first = [0, 100000, 170000, 201744]
+    first = [0, 100000, 170000, 210000]
     for r in range(4):
         assert (first[r] + skip[r]) % shard.BLOCK_TOKENS == 0
         owned = counts[r] - skip[r] + tail[r]
         if r < 3:
             assert owned % shard.BLOCK_TOKENS == 0
     assert tail[:3] == skip[1:]
+    import pytest
+    with pytest.raises(ValueError):
+        shard.p1_token_split([100000, 5, 100000])
     # entries: a rank whose range is jumped over keeps the incoming position
     lays = [dict(a=0, b=1000), dict(a=1000, b=1200), dict(a=1200, b=3000)]
     tabs = [[300] * shard.ZONE, [7] * shard.ZONE, [0] * shard.ZONE]
     assert shard.p1_entries(lays, tabs) == [0, 1300, 1300]
     # layouts cover the input with history and look-ahead clipped to it
-    for total in (100, 5_000_000):
-        for world in (1, 3):
+    for total in (5_000_000, 40_000_001):
+        for world in (1, 3, 8):
             ls = [shard.p1_layout(total, r, world) for r in range(world)]
             assert ls[0]["g_lo"] == 0 and ls[-1]["g_hi"] == total
             for L in ls:
