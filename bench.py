@@ -58,13 +58,21 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # MI355_BENCH_BACKEND=gloo lets several ranks share one GPU (dry run of the N > 1 path on a 1-GPU box):
+    # exchanged tensors then travel through host memory; the default is RCCL over xGMI.
+    backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     size = args.size or {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024}[args.workload]
+    shard_mode = os.environ.get("MI355_SHARD_MODE", "p1") if world > 1 else "single"
+    if world > 1:
+        size = (size + 32767) // 32768 * 32768  # rank ranges of the one big input are 32 KiB aligned
     lvl = args.level or ("rle" if args.workload == "zeros" else "default")
     options = {"default": da.CompressionOptions.default, "best": da.CompressionOptions.high,
                "fast": da.CompressionOptions.fast, "rle": da.CompressionOptions.rle,
@@ -76,9 +84,38 @@ def main():
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     cap = da.bound(size) + 8
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    ctx = da.Context(local_rank)
+    ctx = da.Context(dev_index)
     stream = torch.cuda.current_stream().cuda_stream
     flush = shard.flush_mode_for(rank, world)
+    total = world * size
+    layout = None
+    d_ext = None
+    if shard_mode == "p1":
+        # The one big input is the concatenation of the ranks' shards; a rank also holds 32 KiB of history
+        # from its left neighbour and 66 KiB of look-ahead from its right one (exchanged once, untimed).
+        layout = shard.p1_layout(total, rank, world)
+        parts = []
+        if rank > 0:
+            prev = torch.empty(shard.HISTORY, dtype=torch.uint8, device=cdev)
+        if rank < world - 1:
+            nxt = torch.empty(shard.LOOKAHEAD, dtype=torch.uint8, device=cdev)
+        reqs = []
+        if rank < world - 1:
+            reqs.append(dist.isend(d_in[size - shard.HISTORY:].to(cdev).contiguous(), dst=rank + 1))
+        if rank > 0:
+            reqs.append(dist.isend(d_in[: shard.LOOKAHEAD].to(cdev).contiguous(), dst=rank - 1))
+        if rank > 0:
+            dist.recv(prev, src=rank - 1)
+            parts.append(prev.cuda())
+        parts.append(d_in)
+        if rank < world - 1:
+            dist.recv(nxt, src=rank + 1)
+            parts.append(nxt.cuda())
+        for q in reqs:
+            q.wait()
+        parts.append(torch.zeros(64, dtype=torch.uint8, device="cuda"))
+        d_ext = torch.cat(parts)
+        assert d_ext.numel() - 64 == layout["g_hi"] - layout["g_lo"]
 
     out_len = [0]
     match_ms = []
@@ -86,6 +123,14 @@ def main():
     gpu_ms = []
 
     def step(record):
+        if shard_mode == "p1":
+            _, n = shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev)
+            out_len[0] = n if rank == 0 else 0
+            if record:
+                info = ctx.info()
+                match_ms.append(info["match_ms"] / max(1, info["match_launches"]))
+                gpu_ms.append(info["total_ms"])
+            return
         n = ctx.encode_device(d_in.data_ptr(), size, d_out.data_ptr(), cap, options, stream=stream, flush=flush)
         out_len[0] = n
         if record:
@@ -95,7 +140,7 @@ def main():
             for k, v in info["stage_ms"].items():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
         if world > 1:
-            shard.stitch(d_out, n, rank, world)
+            shard.stitch(d_out if cdev == "cuda" else d_out.cpu(), n, rank, world)
 
     for _ in range(args.warmup):
         step(False)
@@ -110,12 +155,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot_out = torch.tensor([out_len[0]], dtype=torch.int64, device="cuda")
+        tot_out = torch.tensor([out_len[0]], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot_out)
-        total_out = int(tot_out.item())
+        total_out = int(tot_out.item())  # p1: only rank 0 reports the (whole) stream length
     else:
         total_out = out_len[0]
 
@@ -124,7 +169,8 @@ def main():
         value = world * size * args.steps / elapsed / 1e6
         mm = sum(match_ms) / len(match_ms)
         dominant = "k_rle" if lvl == "rle" else "k_match"
-        algo_bytes = size + out_len[0]  # 1 B read + r B written per input byte, one launch = one input
+        # 1 B read + r B written per input byte; one launch of the dominant kernel = one rank's bytes
+        algo_bytes = size + (total_out // world)
         achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0
         traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes
         try:
@@ -138,8 +184,11 @@ def main():
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d bytes per GPU, %s, stream-exact (P1) per GPU%s" % (
-                args.workload, size, level_name, "" if world == 1 else ", chunk-exact (P2) stitch across GPUs"),
+            "config": {"workload": "%s: %d bytes per GPU, %s, %s" % (
+                args.workload, size, level_name,
+                "stream-exact (P1)" if world == 1 else (
+                    "one %d-byte input sharded over %d GPUs, stream-exact (P1), RCCL stitch" % (total, world)
+                    if shard_mode == "p1" else "chunk-exact (P2) stitch across GPUs")),
                 "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % world},
             "out_bytes": total_out, "ratio": round(total_out / (world * size), 5),
             "gpu_ms_per_step_events": round(sum(gpu_ms) / len(gpu_ms), 3),

@@ -153,56 +153,56 @@ def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
     return bytes(out[: (total_bits + 7) // 8].numpy())
 
 
-def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, compat=0, group=None):
+def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, compat=0, group=None, comm_device=None):
     """One rank of the distributed driver.  d_ext: uint8 device tensor holding bytes [g_lo, g_hi) of the
-    input (+ >= 16 bytes of slack).  Returns (tensor on rank 0 | None, stream length in bytes)."""
+    input (+ >= 16 bytes of slack).  comm_device: where exchanged tensors live -- the GPU for the nccl
+    (= RCCL) backend, "cpu" for gloo.  Returns (tensor on rank 0 | None, stream length in bytes)."""
     import torch
     options = options if options is not None else da.Compression.Default
     dev = d_ext.device
+    cdev = torch.device(comm_device) if comm_device is not None else dev
     L = layout
+
+    def gather_ints(vals):
+        mine = torch.tensor(vals, dtype=torch.int64, device=cdev)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine, group=group)
+        return [t.tolist() for t in allv]
+
     sh = da.Shard(ctx, d_ext.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total, options, compat,
-                  torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0)
-    # exchange 1: exit tables
-    mine = torch.tensor(sh.exit_table(), dtype=torch.int64, device=dev)
-    allt = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(allt, mine, group=group)
+                  torch.cuda.current_stream(dev).cuda_stream)
+    # exchange 1: exit tables -> entry positions
+    tables = gather_ints(sh.exit_table())
     lays = [p1_layout(total, r, world) for r in range(world)]
-    entries = p1_entries(lays, [t.tolist() for t in allt])
+    entries = p1_entries(lays, tables)
     n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
     # exchange 2: token counts
-    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(cnt, torch.tensor([n_tok], dtype=torch.int64, device=dev), group=group)
-    counts = [int(c.item()) for c in cnt]
+    counts = [c[0] for c in gather_ints([n_tok])]
     skip, tail = p1_token_split(counts)
     # exchange 3: the head tokens of rank r+1 complete the last block of rank r
-    import ctypes
     reqs = []
-    head = None
     if rank > 0 and skip[rank]:
         head = torch.empty(skip[rank], dtype=torch.int32, device=dev)
         ctypes_copy_d2d(head.data_ptr(), tok_ptr, skip[rank] * 4)
-        reqs.append(dist.isend(head, dst=rank - 1, group=group))
+        head_c = head.to(cdev)
+        reqs.append(dist.isend(head_c, dst=rank - 1, group=group))
     tail_t = None
     if tail[rank]:
-        tail_t = torch.empty(tail[rank], dtype=torch.int32, device=dev)
-        dist.recv(tail_t, src=rank + 1, group=group)
+        tail_c = torch.empty(tail[rank], dtype=torch.int32, device=cdev)
+        dist.recv(tail_c, src=rank + 1, group=group)
+        tail_t = tail_c.to(dev)
     for q in reqs:
         q.wait()
     costs = sh.blocks(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
     # exchange 4: block costs (6 x int64 per block), padded to the largest rank
-    nbs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(nbs, torch.tensor([len(costs)], dtype=torch.int64, device=dev), group=group)
-    nbs = [int(x.item()) for x in nbs]
+    nbs = [c[0] for c in gather_ints([len(costs)])]
     mx = max(1, max(nbs))
-    flat = torch.zeros(mx * 6, dtype=torch.int64, device=dev)
-    if costs:
-        flat[: len(costs) * 6] = torch.tensor([v for c in costs for v in c], dtype=torch.int64, device=dev)
-    allc_t = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(allc_t, flat, group=group)
+    flat = [0] * (mx * 6)
+    flat[: len(costs) * 6] = [int(v) for c in costs for v in c]
+    allf = gather_ints(flat)
     allc = []
     for r in range(world):
-        v = allc_t[r][: nbs[r] * 6].tolist()
-        allc.extend(tuple(v[i * 6:(i + 1) * 6]) for i in range(nbs[r]))
+        allc.extend(tuple(allf[r][i * 6:(i + 1) * 6]) for i in range(nbs[r]))
     plans, total_bits = da.plan_blocks(allc, compat)
     b0 = sum(nbs[:rank])
     mine_p = plans[b0:b0 + nbs[rank]]
@@ -215,9 +215,7 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         fb, nbytes = sh.pack(mine_p, end_bit, dev_out.data_ptr(), cap)
     sh.close()
     # exchange 5: byte ranges to rank 0, OR-ed (neighbours share the seam word)
-    meta = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(meta, torch.tensor([fb, nbytes], dtype=torch.int64, device=dev), group=group)
-    meta = [(int(m[0].item()), int(m[1].item())) for m in meta]
+    meta = gather_ints([fb, nbytes])
     stream_len = (total_bits + 7) // 8
     if rank == 0:
         out = torch.zeros(stream_len + 16, dtype=torch.uint8, device=dev)
@@ -226,12 +224,12 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         for r in range(1, world):
             f, k = meta[r]
             if k:
-                tmp = torch.empty(k, dtype=torch.uint8, device=dev)
+                tmp = torch.empty(k, dtype=torch.uint8, device=cdev)
                 dist.recv(tmp, src=r, group=group)
-                out[f:f + k] |= tmp
+                out[f:f + k] |= tmp.to(dev)
         return out[:stream_len], stream_len
     if nbytes:
-        dist.send(dev_out[:nbytes].contiguous(), dst=0, group=group)
+        dist.send(dev_out[:nbytes].to(cdev).contiguous(), dst=0, group=group)
     return None, stream_len
 
 

@@ -311,3 +311,46 @@ def test_p1_sharded_stream_exact(da, world):
     finally:
         for c in ctxs:
             c.close()
+
+
+def _p1_dist_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd"))
+    sys.path.insert(0, HERE)
+    import datagen as dg
+    import deflate_amd as da
+    import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = dg.text_like(6_000_000, 77)  # every rank regenerates the same input and keeps its slice
+    total = len(data)
+    L = shard.p1_layout(total, rank, world)
+    d_ext = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).cuda()
+    ctx = da.Context(0)
+    out, n = shard.encode_p1_dist(da, ctx, d_ext, L, total, rank, world, da.Compression.Default, compat=1,
+                                  comm_device="cpu")
+    if rank == 0:
+        import oracle_binding as ob2
+        q.put(bytes(out.cpu().numpy()) == ob2.encode(data, level=ob2.DEFAULT))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# the distributed driver itself (torch.distributed, gloo here; RCCL on a multi-GPU node), three processes
+# sharing this one GPU
+def test_p1_distributed_driver_gloo():
+    import torch.multiprocessing as mp
+    world = 3
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [mctx.Process(target=_p1_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ok
