@@ -257,11 +257,22 @@ struct WavePolicy {
     }
 };
 
+// end of the visible data for a window-relative position (segment end of the absolute position)
+struct TileLimit {
+    SegEnds sg;
+    uint64_t wstart;
+    __device__ uint32_t operator()(uint32_t idx) const {
+        uint64_t e = seg_end(sg, wstart + idx);
+        uint64_t r = e - wstart;
+        return r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;
+    }
+};
+
 template <bool HAS_Q>
 __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ in, uint32_t n,
                                                     const uint16_t* __restrict__ link, uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
-                                                    int in_aligned4) {
+                                                    int in_aligned4, SegEnds sg) {
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[MW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_link[MW_LINKS];
     __shared__ uint32_t s_next;
@@ -316,11 +327,10 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
     __syncthreads();
     LdsWin win{s_bytes, s_link};
     MatchEmit emit{M, HAS_Q ? Mq : nullptr, wstart};
-    uint64_t nrel64 = (uint64_t)n - wstart;
-    uint32_t nrel = nrel64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nrel64;
     TileNext next{&s_next, (uint32_t)(E - wstart), MT};
     WavePolicy pol;
-    match_walk_park<MCHAINS, HAS_Q>(win, next, nrel, checks, checks_q, emit, pol);
+    TileLimit lim{sg, wstart};
+    match_walk_park<MCHAINS, HAS_Q>(win, next, lim, checks, checks_q, emit, pol);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,7 +339,8 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
 // positions: one forward scan of at most 258 bytes past its chunk, then a backward recurrence.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t RT = 4096;
-__global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ R) {
+__global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ R,
+                                             SegEnds sg) {
     __shared__ __attribute__((aligned(16))) uint8_t s[RT + 258 + 16];  // s[i] = in[E - 1 + i]
     const uint32_t tid = threadIdx.x;
     const uint64_t E = (uint64_t)blockIdx.x * RT;
@@ -351,7 +362,14 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
         uint64_t g = E + pr;
         c = eq(pr) ? c + 1 : 0;
         if (c > 65535) c = 65535;
-        if (g < n) R[g] = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
+        if (g < n) {
+            uint32_t r = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
+            if (sg.m > 1) {  // a run is cut where the data the encoder had ended (sync flush)
+                uint64_t left = (uint64_t)seg_end(sg, g) - g;
+                if (r > left) r = (uint32_t)left;
+            }
+            R[g] = r;
+        }
     }
 }
 
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 // get before it is again in a state that depends on the position only.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
-                                             ParseCfg cfg, uint16_t* __restrict__ adv) {
+                                             ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg) {
     // four consecutive positions per lane: 16-byte loads of M, one 8-byte store of adv
     uint64_t j0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (j0 >= n) return;
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
     uint16_t a[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        if (j0 + q < n) a[q] = (uint16_t)parse_step(m, mq, j0 + q, (uint64_t)n, cfg).adv;
+        if (j0 + q < n) a[q] = (uint16_t)parse_step(m, mq, j0 + q, (uint64_t)seg_end(sg, j0 + q), cfg).adv;
     if (j0 + 4 <= n) {
         uint2 v = make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
         *reinterpret_cast<uint2*>(adv + j0) = v;  // adv is 256-byte aligned, j0 a multiple of 4
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                                               const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
                                               const uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
-                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total) {
+                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg) {
     __shared__ uint16_t s_adv[4][SEG];
     __shared__ uint16_t s_pp[4][SEG];
     __shared__ uint32_t s_np[4];
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         uint64_t j = 0;
         if (have) {
             j = (uint64_t)pos0 + a + s_pp[wv][idx];
-            st = parse_step(m, mq, j, (uint64_t)n_total, cfg);
+            st = parse_step(m, mq, j, (uint64_t)seg_end(sg, j), cfg);
         }
         uint32_t ntok = st.nlit + (st.mlen ? 1u : 0u);
         uint32_t incl = ntok;
@@ -594,30 +612,93 @@ __device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_block_bounds: where each 31744-token block (output_writer.rs:19,38-44) starts in the input,
-// the data for the Q1 decision, and the Q13 condition per block.
+// Block table.  Blocks are "every 31744 tokens" (output_writer.rs:19,38-44) inside each segment of
+// the input (a sync flush ends the current block, compress.rs:256-261); a segment whose token count
+// is a multiple of 31744 -- including an empty one -- still ends with one (empty) block, because the
+// reference only learns that the data is over on the next call (lz77.rs:709-742, A.4 Q8).
+//   k_seg_tokens   tokens that start before each segment end (the parse passes through every end)
+//   k_block_count  blocks per segment, prefix sum, total
+//   k_block_bounds per block: token range, start position in the input, sync-marker flag, the data
+//                  for the Q1 decision and the Q13 condition
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode,
-                                                     const uint32_t* __restrict__ base, const uint32_t* __restrict__ E0,
-                                                     const uint32_t* __restrict__ tokbuf,
+struct BlockTab {
+    uint32_t* t0;    // first token
+    uint32_t* nt;    // token count (0..31744)
+    uint32_t* sync;  // 1 = the empty stored block 00 00 FF FF follows (compress.rs:258-261)
+};
+
+__global__ __launch_bounds__(64) void k_seg_tokens(SegEnds sg, uint32_t K, const uint32_t* __restrict__ base,
+                                                   const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
+                                                   const uint32_t* __restrict__ cnt, const DevScalars* sc,
+                                                   uint32_t* __restrict__ tend) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= sg.m) return;
+    uint32_t e = sg.ends[i];
+    if (i + 1 == sg.m || K == 0) {
+        tend[i] = sc->T;
+        return;
+    }
+    uint32_t k = e / SEG;
+    if (k >= K) {
+        tend[i] = sc->T;
+        return;
+    }
+    uint32_t pos = E0[k], c = 0, nk = cnt[k];
+    const uint32_t* tk = tokbuf + (uint64_t)k * SEG;
+    while (pos < e && c < nk) pos += tok_cover(tk[c++]);
+    tend[i] = base[k] + c;
+}
+
+__global__ void k_block_count(SegEnds sg, const uint32_t* __restrict__ tend, uint32_t* __restrict__ pb, DevScalars* sc) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t acc = 0, prev = 0;
+    for (uint32_t i = 0; i < sg.m; i++) {
+        pb[i] = acc;
+        acc += (tend[i] - prev) / MAX_BUFFER_LENGTH + 1;
+        prev = tend[i];
+    }
+    pb[sg.m] = acc;
+    sc->nb = acc;
+}
+
+__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode, SegEnds sg,
+                                                     uint32_t sync_final, const uint32_t* __restrict__ tend,
+                                                     const uint32_t* __restrict__ pb, const uint32_t* __restrict__ base,
+                                                     const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
                                                      const uint32_t* __restrict__ dtok, DevScalars* sc,
-                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13) {
+                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13,
+                                                     BlockTab tab) {
     uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b > nb_max) return;
-    uint32_t T = sc->T, nb = sc->nb;
+    const uint32_t nb = sc->nb;
     if (b > nb) return;
     if (b == nb) {
         bstart[b] = n;
         return;
     }
-    uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
-    bstart[b] = t0 < T ? token_start((uint32_t)t0, K, base, E0, tokbuf) : n;
+    uint32_t lo = 0, hi = sg.m;  // segment i with pb[i] <= b < pb[i+1]
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (pb[mid] <= b)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t i = lo, j = b - pb[i], nbi = pb[i + 1] - pb[i];
+    const uint32_t tprev = i ? tend[i - 1] : 0;
+    const uint32_t t0 = tprev + j * MAX_BUFFER_LENGTH;
+    const uint32_t left = tend[i] - t0;
+    const uint32_t nt = left < MAX_BUFFER_LENGTH ? left : (uint32_t)MAX_BUFFER_LENGTH;
+    tab.t0[b] = t0;
+    tab.nt[b] = nt;
+    tab.sync[b] = (j + 1 == nbi && (i + 1 < sg.m || sync_final)) ? 1u : 0u;
+    bstart[b] = nt ? token_start(t0, K, base, E0, tokbuf) : sg.ends[i];
     uint32_t flag = 0;
-    if (t0 + MAX_BUFFER_LENGTH <= T) {  // a full block: look at its last token
-        uint32_t t1 = (uint32_t)(t0 + MAX_BUFFER_LENGTH - 1);
+    if (nt == MAX_BUFFER_LENGTH) {  // a full block: look at its last token
+        uint32_t t1 = t0 + MAX_BUFFER_LENGTH - 1;
         uint32_t tk = dtok[t1];
         uint32_t tp = token_start(t1, K, base, E0, tokbuf);
-        if (b == 0) {
+        if (tp < WINDOW_SIZE) {  // the one block that can fill inside the first window (Q1, lz77.rs:628-638)
             sc->b0_full = 1;
             sc->b0_last_tok = tk;
             sc->b0_last_pos = tp;
@@ -629,7 +710,8 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uin
             uint64_t mend = (uint64_t)tp + tok_cover(tk);
             if (wdx >= 1 && mend > wend) {
                 uint64_t buf_end = wdx * (uint64_t)WINDOW_SIZE + 65794;
-                if (buf_end > n) buf_end = n;
+                uint64_t have = sg.ends[i];  // the data the encoder held when this block ended
+                if (buf_end > have) buf_end = have;
                 flag = (mend + WINDOW_SIZE > buf_end) ? 2u : 1u;
             }
         }
@@ -637,19 +719,31 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uin
     q13[b] = flag;
 }
 
+// the implicit table of the sharded path: blocks of 31744 tokens, no sync markers
+__global__ __launch_bounds__(256) void k_block_table_uniform(uint64_t T2, uint32_t nb2, BlockTab tab) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb2) return;
+    uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
+    uint64_t left = T2 > t0 ? T2 - t0 : 0;
+    tab.t0[b] = (uint32_t)t0;
+    tab.nt[b] = left < MAX_BUFFER_LENGTH ? (uint32_t)left : (uint32_t)MAX_BUFFER_LENGTH;
+    tab.sync[b] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_block_hist: output_writer.rs:47-65,75-85 -- literal/length and distance frequencies of one
 // block, reduced in LDS.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
-                                                    uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq) {
+                                                    uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq,
+                                                    BlockTab tab) {
     __shared__ uint32_t h[320];
     uint32_t b = blockIdx.x;
     if (b >= sc->nb) return;
     for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
     __syncthreads();
-    uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
-    uint64_t t1 = t0 + MAX_BUFFER_LENGTH < sc->T ? t0 + MAX_BUFFER_LENGTH : sc->T;
+    uint64_t t0 = tab.t0[b];
+    uint64_t t1 = t0 + tab.nt[b];
     for (uint64_t t = t0 + threadIdx.x; t < t1; t += 256) {
         uint32_t tk = dtok[t];
         if (tk >> 16) {
@@ -770,7 +864,7 @@ __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint6
 __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
                                              const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
                                              BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
-                                             uint32_t sync_tail, uint32_t* __restrict__ out32) {
+                                             const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32) {
     const uint32_t lane = threadIdx.x;
     const uint32_t nb = sc->nb;
     uint64_t bitpos = bit_base;
@@ -792,9 +886,16 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             uint64_t len = 0;
             if (lane == sidx) {
                 BlockPlan p;
-                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == nb) && !sync_tail, bitpos, &p);
+                const bool sync = blk_sync[b] != 0;
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == nb) && !sync, bitpos, &p);
                 plan[b] = p;
                 len = p.bit_len;
+                if (sync) {  // compress.rs:256-261: empty stored block = 3 zero bits, pad, 00 00 FF FF
+                    uint64_t e = bitpos + len;
+                    uint64_t hb = (e + 3 + 7) & ~7ull;
+                    put_bits(out32, hb, 0xFFFF0000ull, 32);
+                    len = hb + 32 - bitpos;
+                }
                 if (p.btype == BT_STORED) {
                     n_st++;
                     if (q13[b]) {
@@ -820,11 +921,6 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         panic |= __shfl_down(panic, off);
     }
     if (lane == 0) {
-        if (sync_tail) {  // compress.rs:256-261: empty stored block = 3 zero bits, pad, 00 00 FF FF
-            uint64_t hb = (bitpos + 3 + 7) & ~7ull;
-            put_bits(out32, hb, 0xFFFF0000ull, 32);
-            bitpos = hb + 32;
-        }
         sc->total_bits = bitpos - bit_base;
         sc->n_stored = n_st;
         sc->n_fixed = n_fx;
@@ -866,7 +962,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
                                               const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                               const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
-                                              uint32_t compat, uint32_t* __restrict__ out32) {
+                                              uint32_t compat, uint32_t* __restrict__ out32, BlockTab tab) {
     __shared__ PackLds s;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     if (b >= sc->nb) return;
@@ -959,8 +1055,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
     bp += hdr_bits;
     // tokens: 4 consecutive tokens per lane and round; lengths are scanned inside the wave with
     // shuffles and across the 4 waves through LDS (two barriers per 1024 tokens)
-    const uint64_t t0 = (uint64_t)b * MAX_BUFFER_LENGTH;
-    const uint64_t t1 = t0 + MAX_BUFFER_LENGTH < sc->T ? t0 + MAX_BUFFER_LENGTH : sc->T;
+    const uint64_t t0 = tab.t0[b];
+    const uint64_t t1 = t0 + tab.nt[b];
     const uint32_t lane = tid & 63, wv = tid >> 6;
     for (uint64_t tb = t0; tb < t1; tb += 1024) {
         uint64_t tq = tb + 4ull * tid;

@@ -269,8 +269,16 @@ struct ServiceAlways {  // host policy: service parked / finished slots at once,
     MI355_HD bool keep_extending(bool any, uint32_t /*round*/) const { return any; }
 };
 
-template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy>
-MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t checks, uint32_t checks_q, Emit& emit,
+// `lim(idx)` = end of the data the encoder had when it searched position idx (W's index space): the
+// end of input, or the next flush point (a sync flush makes the reference parse what it has, so
+// matches and hash bytes stop there: lz77.rs:593,627).
+struct ConstLimit {
+    uint32_t n;
+    MI355_HD uint32_t operator()(uint32_t) const { return n; }
+};
+
+template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy, class Lim>
+MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t checks, uint32_t checks_q, Emit& emit,
                               const Policy& policy) {
     enum : uint32_t { IDLE = 0, WALK = 1, PARK = 2, FIN = 3 };
     uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], st[U], dsave[U], len[U], mq[U];
@@ -306,6 +314,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, uint32_t nrel, uint32_t ch
             st[s] = IDLE;
             uint32_t idx = next();
             if (idx == NO_POS) return;
+            const uint32_t nrel = lim(idx);
             if (idx >= nrel) continue;
             if (idx + 2 >= nrel) {  // no hash byte: never searched (lz77.rs:294-301)
                 emit(idx, 0u, 0u);
@@ -448,6 +457,26 @@ MI355_HD uint32_t rle_run(const Bytes& by, uint64_t p, uint64_t n) {
     uint32_t c = 0;
     while (c < cap && by(p + c) == prev) c++;
     return c;
+}
+
+// ---- segment ends (sync flush points) -------------------------------------------------------------
+// ends[0] <= ends[1] <= ... <= ends[m-1] = n: the input as the encoder saw it arrive.  A position p
+// belongs to the segment that ends at the first ends[i] > p.  m == 1 is the one-shot case.
+struct SegEnds {
+    const uint32_t* ends;
+    uint32_t m;
+};
+MI355_HD uint32_t seg_end(const SegEnds& sg, uint64_t p) {
+    if (sg.m == 1) return sg.ends[0];
+    uint32_t lo = 0, hi = sg.m - 1;  // first i with ends[i] > p (p < ends[m-1] for every real position)
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sg.ends[mid] > p)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return sg.ends[lo];
 }
 
 // ---- the parser as a restart transducer ---------------------------------------------------

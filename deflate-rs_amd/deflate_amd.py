@@ -147,6 +147,7 @@ def load():
     L.mi355_adler32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
     L.mi355_deflate_stream_new.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
     L.mi355_deflate_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mi355_deflate_stream_flush.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_finish.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_output.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t)]
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -160,7 +161,8 @@ EXPORTED = [
     "mi355_deflate_version", "mi355_deflate_bound", "mi355_deflate_preset", "mi355_deflate_ctx_create",
     "mi355_deflate_ctx_destroy", "mi355_deflate_last_error", "mi355_deflate_encode",
     "mi355_deflate_encode_device", "mi355_deflate_last_info", "mi355_deflate_last_blocks", "mi355_adler32_device",
-    "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_finish",
+    "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_flush",
+    "mi355_deflate_stream_finish",
     "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
     "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end",
@@ -305,6 +307,12 @@ class _Encoder:
         return len(buf)
 
     write_all = write
+
+    def flush(self):
+        """io::Write::flush = Flush::Sync (writer.rs:134-137): sync marker, window kept"""
+        rc = load().mi355_deflate_stream_flush(self._s)
+        if rc != OK:
+            raise DeflateError(rc, "stream_flush")
 
     def finish(self):
         """finish(self) -> W (writer.rs:103-108, 209-214)"""

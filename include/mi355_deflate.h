@@ -184,11 +184,16 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  *   _output   = the bytes W = Vec<u8> would hold
  *   _checksum = ZlibEncoder::checksum()              :248-250
  * Output is independent of how the input is split across writes (the reference guarantees the
- * same: src/lz77.rs:627, test src/lib.rs:408-433), so writes are gathered and encoded on the
- * GPU at finish().  flush() (Flush::Sync) and reset() are not implemented in this round. */
+ * same: src/lz77.rs:627, test src/lib.rs:408-433), so writes (and flush points) are gathered and
+ * encoded on the GPU at finish().  reset() is not implemented in this round. */
 typedef struct mi355_deflate_stream mi355_deflate_stream;
 int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* opts, mi355_deflate_stream** out);
 int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);
+/* io::Write::flush (Flush::Sync, src/writer.rs:134-137, 274-277; src/compress.rs:256-261; src/lz77.rs:
+ * 605-614, 728-740): what was written so far is emitted in non-final blocks + 00 00 FF FF, the window
+ * is kept.  Two write patterns whose hash-table side effects are not reproduced make finish() return
+ * MI355_E_UNSUPPORTED: a flush after only 1-2 bytes, and a 1-byte write right after a flush. */
+int mi355_deflate_stream_flush(mi355_deflate_stream* s);
 int mi355_deflate_stream_finish(mi355_deflate_stream* s);
 int mi355_deflate_stream_output(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
 int mi355_deflate_stream_checksum(mi355_deflate_stream* s, uint32_t* adler);

@@ -100,16 +100,16 @@ void stage_match(Sim& s) {
                     bool keep_extending(bool any, uint32_t round) const { return any && round < 1; }
                 } pol;
                 if (hasq)
-                    match_walk_park<4, true>(w, next, (uint32_t)s.n, s.cfg.checks, cq, emit, pol);
+                    match_walk_park<4, true>(w, next, ConstLimit{(uint32_t)s.n}, s.cfg.checks, cq, emit, pol);
                 else
-                    match_walk_park<4, false>(w, next, (uint32_t)s.n, s.cfg.checks, 0, emit, pol);
+                    match_walk_park<4, false>(w, next, ConstLimit{(uint32_t)s.n}, s.cfg.checks, 0, emit, pol);
                 continue;
             }
             ServiceAlways pol;
             if (hasq)
-                match_walk_park<4, true>(w, next, (uint32_t)s.n, s.cfg.checks, cq, emit, pol);
+                match_walk_park<4, true>(w, next, ConstLimit{(uint32_t)s.n}, s.cfg.checks, cq, emit, pol);
             else
-                match_walk_park<4, false>(w, next, (uint32_t)s.n, s.cfg.checks, 0, emit, pol);
+                match_walk_park<4, false>(w, next, ConstLimit{(uint32_t)s.n}, s.cfg.checks, 0, emit, pol);
         }
         if (s.cfg.use_quarter && cq == 0)
             for (uint64_t p = 0; p < s.n; p++) s.Mq[p] = 0;

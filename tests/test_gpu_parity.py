@@ -354,3 +354,73 @@ def test_p1_distributed_driver_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert ok
+
+
+# flush() = Flush::Sync with window retention (writer.rs:134-137, 571-660; tests/test.rs:113-123
+# issue_26 "write after flush"): the GPU stream must equal the reference encoder driven with the same
+# write/flush sequence.
+def _drive(enc_new, ref_new, data, cuts, flush_at_end=False):
+    import io
+    enc = enc_new()
+    ref = ref_new()
+    prev = 0
+    for c in cuts:
+        enc.write_all(data[prev:c])
+        ref.write_all(data[prev:c])
+        enc.flush()
+        ref.flush()
+        prev = c
+    enc.write_all(data[prev:])
+    ref.write_all(data[prev:])
+    if flush_at_end:
+        enc.flush()
+        ref.flush()
+    got = enc.finish().getvalue()
+    exp = ref.finish()
+    assert got == exp, "stream with flush points %s differs (%d vs %d bytes)" % (cuts, len(got), len(exp))
+    return got
+
+
+@pytest.mark.parametrize("level", ["default", "fast", "rle", "best"])
+def test_flush_with_window_retention(da, ctx, level):
+    import io
+    import random
+    c, l, m = LV[level]
+    rnd = random.Random(5)
+    texts = [datagen.text_like(260000 if level != "best" else 120000, 41), datagen.mixed(200000, 12),
+             datagen.rng_bytes(90000, 13), bytes(150000)]
+    for data in texts:
+        n = len(data)
+        cut_sets = [[n // 3], [1000, 70000], [0], [5, 5, 40000], [n - 3], [32768, 65536, 65537 + 2],
+                    sorted(rnd.sample(range(3, n - 3), 6))]
+        for cuts in cut_sets:
+            # every write after a flush must carry >= 2 bytes (the 1-byte quirk is refused, tested below)
+            ok = all(b - a != 1 for a, b in zip(cuts, cuts[1:] + [n])) and all(x == 0 or x >= 3 for x in cuts)
+            if not ok:
+                continue
+            for wrapper, cls in ((0, da.DeflateEncoder), (1, da.ZlibEncoder)):
+                got = _drive(lambda: cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx),
+                             lambda: ob.Stream(ob.make_opts(c, l, m, wrapper)), data, cuts,
+                             flush_at_end=(cuts == [n // 3]))
+                if wrapper:
+                    assert zlib.decompress(got) == data
+                else:
+                    assert inflate_raw(got) == data
+    # later data may match across the flush point: the stream with a flush is smaller than two streams
+    data = datagen.text_like(100000, 42) * 2
+    one = _drive(lambda: da.DeflateEncoder(io.BytesIO(), da.Compression.Default, ctx),
+                 lambda: ob.Stream(ob.preset(ob.DEFAULT)), data, [100000])
+    two = len(ctx.encode(data[:100000])) + len(ctx.encode(data[100000:]))
+    assert len(one) < two * 0.7
+
+
+def test_flush_patterns_that_are_refused(da, ctx):
+    import io
+    enc = da.DeflateEncoder(io.BytesIO(), da.Compression.Default, ctx)
+    enc.write_all(b"x" * 1000)
+    enc.flush()
+    enc.write_all(b"y")  # 1-byte write right after a flush: lz77.rs:605-614 leaves one position unhashed
+    enc.write_all(b"z" * 100)
+    with pytest.raises(da.DeflateError) as e:
+        enc.finish()
+    assert e.value.code == da.E_UNSUPPORTED
