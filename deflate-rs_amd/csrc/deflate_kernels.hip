@@ -106,14 +106,7 @@ __global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in,
     bool active = p + 2 < n;
     uint32_t v = load_u32_clamped(in, p < n ? p : n - 1, n);
     uint32_t a = v & 0xff, b1 = (v >> 8) & 0xff, c = (v >> 16) & 0xff;
-    if (ov.on) {
-        if (p == ov.pos) {
-            a = ov.b0;
-            b1 = ov.b1;
-        } else if (p == ov.pos + 1) {
-            a = ov.b1;
-        }
-    }
+    apply_rewarm(ov, p, a, b1);
     uint32_t h = active ? hash3(a, b1, c) : 0;
     uint64_t peers = __ballot(active);
 #pragma unroll
@@ -138,13 +131,21 @@ __global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in,
 // sees write(g), the writes do not depend on the reads, and the wave waits once per group.
 constexpr int LG = 8;
 
+//
+// `ident`: the reference's head table starts as head[h] = h (chained_hash_table.rs:64-69), so until
+// the first slide an unused bucket sends a chain on to the position numbered like the hash value.
+// With true hashes such a candidate (and everything behind it) differs within the first three
+// bytes and cannot change a result, so it is left out; after a hash re-warm (HashOverride) two
+// positions are filed under hashes unrelated to their bytes, these hops become real candidates,
+// and the first two epochs reproduce them.
 __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict__ link,
-                                                const uint16_t* __restrict__ hl) {
+                                                const uint16_t* __restrict__ hl, uint32_t ident) {
     __shared__ uint16_t head[32768];
     const uint32_t lane = threadIdx.x;
     const uint64_t c0 = (uint64_t)blockIdx.x * WINDOW_SIZE;
     const int64_t base = (int64_t)c0 - WINDOW_SIZE;  // window-relative 0
-    for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0xFFFF;
+    const bool id = ident && blockIdx.x < 2;
+    for (uint32_t i = lane; i < 32768; i += 64) head[i] = id ? (uint16_t)((int64_t)i - base) : (uint16_t)0xFFFF;
     __syncthreads();
     uint64_t start = base < 0 ? 0 : (uint64_t)base;
     uint64_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;

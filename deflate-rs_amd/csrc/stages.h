@@ -68,23 +68,49 @@ MI355_HD uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) { return ((a & 31u) 
 // Quirk Q1 (lz77.rs:628-638): when the first block fills inside the first window, the rolling
 // hash is re-warmed with data[0], data[1]; the next two inserted positions w, w+1 then hash
 // (b0,b1,d[w+2]) and (b1,d[w+2],d[w+3]).  `on` = 0 in the common case.
+// The same re-warm happens at a sync-flush point F <= 32768 when the write that follows the flush
+// does not itself start processing (add_initial is per call, lz77.rs:601-614): `pts` holds those
+// points, ascending, `m` of them (streaming API only).
 struct HashOverride {
     uint64_t pos;
     uint32_t b0, b1;
     uint32_t on;
+    uint32_t m;
+    const uint32_t* pts;
 };
+
+MI355_HD bool rewarm_listed(const HashOverride& ov, uint32_t p) {
+    uint32_t lo = 0, hi = ov.m;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint32_t v = ov.pts[mid];
+        if (v == p) return true;
+        if (v < p)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return false;
+}
+
+// replaces the first two bytes of position p's 3-byte hash input where a re-warm applies
+MI355_HD void apply_rewarm(const HashOverride& ov, uint64_t p, uint32_t& a, uint32_t& b) {
+    if ((ov.on | ov.m) && p <= WINDOW_SIZE + 1) {
+        bool first = (ov.on && p == ov.pos) || (ov.m && rewarm_listed(ov, (uint32_t)p));
+        bool second = (ov.on && p == ov.pos + 1) || (ov.m && p > 0 && rewarm_listed(ov, (uint32_t)p - 1));
+        if (first) {
+            a = ov.b0;
+            b = ov.b1;
+        } else if (second) {
+            a = ov.b1;
+        }
+    }
+}
 
 template <class Bytes>
 MI355_HD uint32_t position_hash(const Bytes& by, uint64_t p, const HashOverride& ov) {
     uint32_t a = by(p), b = by(p + 1), c = by(p + 2);
-    if (ov.on) {
-        if (p == ov.pos) {
-            a = ov.b0;
-            b = ov.b1;
-        } else if (p == ov.pos + 1) {
-            a = ov.b1;
-        }
-    }
+    apply_rewarm(ov, p, a, b);
     return hash3(a, b, c);
 }
 

@@ -183,9 +183,12 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  *   _finish   = finish(self) -> W                    :103-108 / :209-214
  *   _output   = the bytes W = Vec<u8> would hold
  *   _checksum = ZlibEncoder::checksum()              :248-250
- * Output is independent of how the input is split across writes (the reference guarantees the
- * same: src/lz77.rs:627, test src/lib.rs:408-433), so writes (and flush points) are gathered and
- * encoded on the GPU at finish().  reset() is not implemented in this round. */
+ * Without flush() the output is independent of how the input is split across writes (the reference
+ * guarantees the same: src/lz77.rs:627, test src/lib.rs:408-433), so writes and flush points are
+ * gathered and encoded on the GPU at finish().  One _write call stands for one write_all call
+ * (n == 0: no call at all); the size of the first write after a flush is remembered, because the
+ * reference's hash re-warm at a flush point inside the first window depends on it
+ * (src/lz77.rs:601-638).  reset() is not implemented in this round. */
 typedef struct mi355_deflate_stream mi355_deflate_stream;
 int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* opts, mi355_deflate_stream** out);
 int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);

@@ -38,6 +38,7 @@ struct MAcc {
     uint32_t operator()(uint64_t i) const { return m[i]; }
 };
 
+int g_force_ident = 0;  // walk the identity hops of the head table even without a re-warm
 int g_multi = 0;  // use match_walk_multi (the k_match formulation) instead of match_walk
 
 struct Sim {
@@ -55,11 +56,14 @@ struct Sim {
 void stage_links(Sim& s, const HashOverride& ov) {
     s.link.assign(s.n + 1, 0);
     std::vector<int64_t> head(32768, -1);
+    // identity-initialised head table (chained_hash_table.rs:64-69): matters only after a re-warm
+    if (ov.on | ov.m | (uint32_t)g_force_ident)
+        for (int64_t h = 0; h < 32768; h++) head[h] = h;
     HostBytes by{s.in.data()};
     for (uint64_t p = 0; p + 2 < s.n; p++) {
         uint32_t h = position_hash(by, p, ov);
         int64_t q = head[h];
-        s.link[p] = (q >= 0 && p - (uint64_t)q <= WINDOW_SIZE) ? (uint16_t)(p - (uint64_t)q) : 0;
+        s.link[p] = (q >= 0 && (uint64_t)q < p && p - (uint64_t)q <= WINDOW_SIZE) ? (uint16_t)(p - (uint64_t)q) : 0;
         head[h] = (int64_t)p;
     }
 }
@@ -287,7 +291,7 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
     if (s.cfg.mode == MODE_LAZY && s.cfg.lazy_lt < 3) return -4;  // unsupported
     *flags = 0;
 
-    HashOverride ov = {0, 0, 0, 0};
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr};
     for (int pass = 0; pass < 2; pass++) {
         if (s.cfg.mode != MODE_RLE && checks > 0) stage_links(s, ov);
         stage_match(s);
@@ -476,6 +480,7 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
 }
 
 void hostsim_use_multi(int on) { g_multi = on; }
+void hostsim_force_ident(int on) { g_force_ident = on; }
 
 // expose M for diffing: longest_match(prev_length=0) for every position
 int hostsim_match_table(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t* m_out) {
@@ -487,7 +492,7 @@ int hostsim_match_table(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t
     s.cfg.lazy_lt = 32;
     s.cfg.mode = MODE_LAZY;
     s.cfg.use_quarter = 0;
-    HashOverride ov = {0, 0, 0, 0};
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr};
     stage_links(s, ov);
     stage_match(s);
     for (uint64_t i = 0; i < n; i++) m_out[i] = s.M[i];

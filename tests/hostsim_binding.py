@@ -53,6 +53,11 @@ def use_multi(on):
     lib().hostsim_use_multi(int(on))
 
 
+def force_ident(on):
+    """start from the reference's head[h] = h table and follow those hops (must never change a result)"""
+    lib().hostsim_force_ident(int(on))
+
+
 def match_table(data, checks):
     n = len(data)
     m = (C.c_uint32 * max(n, 1))()

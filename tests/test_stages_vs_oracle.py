@@ -176,3 +176,26 @@ def test_match_walk_formulations_agree(mode):
                 agree(data, *LV[level])
     finally:
         hs.use_multi(0)
+
+
+# The reference's head table starts as head[h] = h, so a chain that runs out of real candidates hops
+# on to the position numbered like its hash value (chained_hash_table.rs:64-69, matching.rs:123-131).
+# DESIGN.md §2.1 claims those hops can never change a match of length >= 3 while hashes are true
+# 3-byte hashes, which is why the kernels skip them unless a hash re-warm is in play; here the hops
+# are forced on and every stream must stay identical (and equal to the oracle's).
+def test_identity_hops_never_change_output():
+    cases = [datagen.text_like(200000, 3), datagen.mixed(150000, 5), datagen.rng_bytes(100000, 2), bytes(70000),
+             (datagen.rng_bytes(300, 5) * 400), datagen.rng_bytes(31744 * 2 + 100, 31744)]
+    try:
+        for data in cases:
+            for checks in (1, 128, 1768):
+                hs.force_ident(0)
+                a = [m if (m & 0xffff) >= 3 else 0 for m in hs.match_table(data, checks)]
+                hs.force_ident(1)
+                b = [m if (m & 0xffff) >= 3 else 0 for m in hs.match_table(data, checks)]
+                assert a == b
+            hs.force_ident(1)
+            for level in ("default", "best", "fast"):
+                agree(data, *LV[level])
+    finally:
+        hs.force_ident(0)
