@@ -14,6 +14,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef MI355_MATCH_STATS
+// instrumented build (tools/variants.sh): per-lane counters of match_walk_park, summed over the launch
+__device__ unsigned long long g_mstats[16];
+#define MI355_STAT_DECL uint32_t stat_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MI355_STAT(i, v) stat_[i] += (v);
+#define MI355_STAT_FLUSH(policy)                                                          \
+    for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_mstats[i_], (unsigned long long)stat_[i_]); \
+    atomicMax((policy).wgmax, stat_[0]);                                                  \
+    if ((threadIdx.x & 63) == 0) {                                                        \
+        unsigned long long t_ = wall_clock64();                                           \
+        atomicMax((policy).wgend, t_);                                                    \
+        atomicAdd((policy).wgsum, t_ - (policy).t0);                                      \
+    }
+#endif
 #include "stages.h"
 
 namespace mi355 {
@@ -246,6 +260,12 @@ struct TileNext {
 // when to service parked / finished slots: every 8th step, or at once when no lane of the wave can
 // walk on (all lanes of a wave iterate in lockstep, so `iter` is uniform)
 struct WavePolicy {
+#ifdef MI355_MATCH_STATS
+    uint32_t* wgmax;
+    unsigned long long* wgend;
+    unsigned long long* wgsum;
+    unsigned long long t0;
+#endif
     __device__ bool operator()(bool pending, bool walking, uint32_t iter) const {
         if ((iter % MI355_MATCH_R) == MI355_MATCH_R - 1) return true;
         return __ballot(walking) == 0;
@@ -325,13 +345,38 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
         reinterpret_cast<uint4*>(s_link)[w] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
     }
     if (tid == 0) s_next = 0;
+#ifdef MI355_MATCH_STATS
+    __shared__ uint32_t s_wgmax;
+    __shared__ unsigned long long s_wgend, s_wgsum;
+    if (tid == 0) {
+        s_wgmax = 0;
+        s_wgend = 0;
+        s_wgsum = 0;
+    }
+    const unsigned long long t_enter = wall_clock64();
+#endif
     __syncthreads();
     LdsWin win{s_bytes, s_link};
     MatchEmit emit{M, HAS_Q ? Mq : nullptr, wstart};
     TileNext next{&s_next, (uint32_t)(E - wstart), MT};
+#ifdef MI355_MATCH_STATS
+    const unsigned long long t_start = wall_clock64();
+    WavePolicy pol{&s_wgmax, &s_wgend, &s_wgsum, t_start};
+#else
     WavePolicy pol;
+#endif
     TileLimit lim{sg, wstart};
     match_walk_park<MCHAINS, HAS_Q>(win, next, lim, checks, checks_q, emit, pol);
+#ifdef MI355_MATCH_STATS
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&g_mstats[8], (unsigned long long)s_wgmax);  // the slowest lane of the workgroup
+        atomicAdd(&g_mstats[9], 1ull);
+        atomicAdd(&g_mstats[10], s_wgend - t_start);   // wall clock (100 MHz) until the last wave ends
+        atomicAdd(&g_mstats[11], s_wgsum);             // sum over the 16 waves of their own end times
+        atomicAdd(&g_mstats[12], t_start - t_enter);   // staging
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

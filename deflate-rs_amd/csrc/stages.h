@@ -303,6 +303,11 @@ struct ConstLimit {
     MI355_HD uint32_t operator()(uint32_t) const { return n; }
 };
 
+#ifndef MI355_STAT
+#define MI355_STAT_DECL
+#define MI355_STAT(i, v)
+#define MI355_STAT_FLUSH(policy)
+#endif
 template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy, class Lim>
 MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t checks, uint32_t checks_q, Emit& emit,
                               const Policy& policy) {
@@ -360,9 +365,21 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             if (st[s] == WALK) return;
         }
     };
+    MI355_STAT_DECL
     MI355_UNROLL
     for (int s = 0; s < U; s++) {
         st[s] = IDLE;
+        p[s] = 0;  // a slot that never gets a position still takes part in the common step's reads
+        cand[s] = 0;
+        best[s] = 1;
+        bestd[s] = 0;
+        probe[s] = 0;
+        it[s] = 0;
+        maxlen[s] = 0;
+        dsave[s] = 0;
+        len[s] = 0;
+        mq[s] = 0;
+        hq[s] = true;
         retire(s);
     }
     for (uint32_t iter = 0;; iter++) {
@@ -371,7 +388,12 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         for (int s = 0; s < U; s++) {
             walking = walking || st[s] == WALK;
             pending = pending || st[s] >= PARK;
+            MI355_STAT(1, st[s] == WALK ? 1u : 0u)
+            MI355_STAT(4, st[s] == PARK ? 1u : 0u)
+            MI355_STAT(5, st[s] == FIN ? 1u : 0u)
+            MI355_STAT(6, st[s] == IDLE ? 1u : 0u)
         }
+        MI355_STAT(0, 1u)
         if (!walking && !pending) break;
         // The common step, branch free: link and probe of the current candidate are read together
         // (for a slot that is not walking the reads are harmless and their results unused), then
@@ -407,6 +429,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             pending = pending || st[s] >= PARK;
         }
         if (!policy(pending, walking, iter)) continue;
+        MI355_STAT(2, 1u)
         // ---- service: get_match_length (matching.rs:67-72) for the parked slots ----
         // (a slot whose compare is cut short by the policy stays parked and goes on next time)
         MI355_UNROLL
@@ -416,6 +439,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             MI355_UNROLL
             for (int s = 0; s < U; s++) any = any || ext[s];
             if (!policy.keep_extending(any, round)) break;
+            MI355_STAT(3, 1u)
             // eight bytes per round trip: most matches on text end inside the first round
             MI355_UNROLL
             for (int s = 0; s < U; s++)
@@ -469,6 +493,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         for (int s = 0; s < U; s++)
             if (st[s] == FIN) retire(s);
     }
+    MI355_STAT_FLUSH(policy)
 #undef MI355_UNROLL
 }
 
