@@ -1,15 +1,18 @@
 """Sharding one input over the GPUs of a node (one process per GPU, torch.distributed; backend
 "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests).
 
-Each rank owns a contiguous byte range of the input and encodes it as one chunk of the final
-stream: every rank but the last ends its chunk with the reference's sync-flush form (all blocks
-non-final + empty stored block, byte aligned; include/mi355_deflate.h MI355_FLUSH_SYNC), the last
-rank finishes normally.  The only exchange on the data path is the final stitch: an all-gather of
-the chunk sizes (8 bytes per rank) and point-to-point sends of the compressed chunks into rank 0's
-output buffer at their byte offsets.  The result equals
-    concat_i  fresh_reference_encoder(chunk_i).write_all().flush()   (finish() for the last)
-i.e. it is chunk-exact ("P2" in SURVEY.md section 0), not identical to the reference run on the
-whole input: matches do not cross rank boundaries.
+Two ways, DESIGN.md section 6:
+
+* stream-exact ("P1", the default of bench.py): the ranks together produce the very bytes one
+  encoder produces for the whole input.  Every rank runs links / match / parse steps on its own
+  byte range (+32 KiB history, +66 KiB look-ahead) and four small exchanges place it in the global
+  stream: exit tables (parse entry), token counts (+ the <= 31 743 tokens of a block that straddles
+  two ranks), per-block costs (every rank then runs the same serial block plan), and the final
+  OR-stitch of the packed byte ranges onto rank 0.  p1_* / encode_p1_* below.
+* chunk-exact ("P2"): every rank encodes its range as one chunk, all but the last in the reference's
+  sync-flush form (include/mi355_deflate.h MI355_FLUSH_SYNC), and the byte-aligned chunks are
+  concatenated on rank 0.  Equal to concat_i fresh_reference_encoder(chunk_i).write_all().flush()
+  (finish() for the last); matches do not cross rank boundaries.  shard_range / stitch below.
 """
 import torch
 import torch.distributed as dist
