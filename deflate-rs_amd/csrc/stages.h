@@ -311,66 +311,23 @@ struct ConstLimit {
 template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy, class Lim>
 MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t checks, uint32_t checks_q, Emit& emit,
                               const Policy& policy) {
+    // WALK: on a chain.  PARK: the current candidate passed the probe and waits for its compare.
+    // FIN: result ready (p == NO_POS: nothing to report), waits to report and to take a new position.
     enum : uint32_t { IDLE = 0, WALK = 1, PARK = 2, FIN = 3 };
     uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], st[U], dsave[U], len[U], mq[U];
     uint32_t rd[U], rv[U], ra[U], rb[U], ra2[U], rb2[U];
-    bool hq[U], ext[U], upd[U];
+    bool hq[U], ext[U];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MI355_UNROLL _Pragma("unroll")
 #else
 #define MI355_UNROLL
 #endif
-    // matching.rs:124-132: the loop header, the link and the two chain-end tests
-    auto follow = [&](int s, uint32_t d) {
-        st[s] = FIN;
-        if (it[s] >= checks) return;
-        if (HAS_Q && !hq[s] && it[s] == checks_q) {
-            mq[s] = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
-            hq[s] = true;
-        }
-        if (d == 0) return;
-        uint32_t c = cand[s] - d;
-        if (p[s] - c > WINDOW_SIZE) return;  // also catches d == 0xFFFF ("none" of link_far)
-        cand[s] = c;
-        it[s]++;
-        st[s] = WALK;
-    };
-    // a finished slot reports its result; then the slot takes positions until one has a candidate
-    auto retire = [&](int s) {
-        for (;;) {
-            if (st[s] == FIN) {
-                uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
-                emit(p[s], m, (HAS_Q && hq[s]) ? mq[s] : m);
-            }
-            st[s] = IDLE;
-            uint32_t idx = next();
-            if (idx == NO_POS) return;
-            const uint32_t nrel = lim(idx);
-            if (idx >= nrel) continue;
-            if (idx + 2 >= nrel) {  // no hash byte: never searched (lz77.rs:294-301)
-                emit(idx, 0u, 0u);
-                continue;
-            }
-            p[s] = idx;
-            cand[s] = idx;
-            best[s] = 1;
-            bestd[s] = 0;
-            probe[s] = w.load32(idx) & 0xffffu;  // bytes 0,1 of P (matching.rs:110,141)
-            it[s] = 0;
-            maxlen[s] = nrel - idx < (uint32_t)MAX_MATCH ? nrel - idx : (uint32_t)MAX_MATCH;
-            mq[s] = 0;
-            hq[s] = !HAS_Q;
-            len[s] = 0;
-            follow(s, w.link(idx));
-            if (st[s] == WALK) return;
-        }
-    };
     MI355_STAT_DECL
     MI355_UNROLL
     for (int s = 0; s < U; s++) {
-        st[s] = IDLE;
-        p[s] = 0;  // a slot that never gets a position still takes part in the common step's reads
-        cand[s] = 0;
+        st[s] = FIN;  // nothing to report yet: the first service hands out the first positions
+        p[s] = NO_POS;
+        cand[s] = 0;  // (every slot takes part in the reads of the common step: keep them in range)
         best[s] = 1;
         bestd[s] = 0;
         probe[s] = 0;
@@ -380,7 +337,6 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         len[s] = 0;
         mq[s] = 0;
         hq[s] = true;
-        retire(s);
     }
     for (uint32_t iter = 0;; iter++) {
         bool walking = false, pending = false;
@@ -430,8 +386,11 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         }
         if (!policy(pending, walking, iter)) continue;
         MI355_STAT(2, 1u)
-        // ---- service: get_match_length (matching.rs:67-72) for the parked slots ----
-        // (a slot whose compare is cut short by the policy stays parked and goes on next time)
+        // ---- service, written as selects as well: the few lanes that need a part of it are spread
+        // over the wave, so every part runs for the whole wave anyway ----
+        // (1) get_match_length (matching.rs:67-72) for the parked slots, eight bytes per round (most
+        // matches on text end inside the first round); a slot whose compare the policy cuts short
+        // stays parked and goes on next time
         MI355_UNROLL
         for (int s = 0; s < U; s++) ext[s] = st[s] == PARK;
         for (uint32_t round = 0;; round++) {
@@ -440,58 +399,92 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             for (int s = 0; s < U; s++) any = any || ext[s];
             if (!policy.keep_extending(any, round)) break;
             MI355_STAT(3, 1u)
-            // eight bytes per round trip: most matches on text end inside the first round
             MI355_UNROLL
-            for (int s = 0; s < U; s++)
-                if (ext[s]) {
-                    ra[s] = w.load32(p[s] + len[s]);
-                    rb[s] = w.load32(cand[s] + len[s]);
-                    ra2[s] = w.load32(p[s] + len[s] + 4);
-                    rb2[s] = w.load32(cand[s] + len[s] + 4);
-                }
+            for (int s = 0; s < U; s++) {
+                const uint32_t a = (p[s] == NO_POS ? 0u : p[s]) + len[s], b = cand[s] + len[s];
+                ra[s] = w.load32(a);
+                rb[s] = w.load32(b);
+                ra2[s] = w.load32(a + 4);
+                rb2[s] = w.load32(b + 4);
+            }
             MI355_UNROLL
-            for (int s = 0; s < U; s++)
-                if (ext[s]) {
-                    uint32_t x = ra[s] ^ rb[s], y = ra2[s] ^ rb2[s];
-                    if (x) {
-                        len[s] += ctz32(x) >> 3;
-                        ext[s] = false;
-                    } else if (y) {
-                        len[s] += 4 + (ctz32(y) >> 3);
-                        ext[s] = false;
-                    } else {
-                        len[s] += 8;
-                    }
-                    if (len[s] >= maxlen[s]) {
-                        len[s] = maxlen[s];
-                        ext[s] = false;
-                    }
-                }
+            for (int s = 0; s < U; s++) {
+                const uint32_t x = ra[s] ^ rb[s], y = ra2[s] ^ rb2[s];
+                const uint32_t n8 = x ? (ctz32(x) >> 3) : (y ? 4u + (ctz32(y) >> 3) : 8u);
+                uint32_t nl = len[s] + n8;
+                nl = nl < maxlen[s] ? nl : maxlen[s];
+                const bool stop = n8 < 8 || nl == maxlen[s];
+                len[s] = ext[s] ? nl : len[s];
+                ext[s] = ext[s] && !stop;
+            }
+        }
+        // (2) matching.rs:149-156 for the compares that are through, then :124-132 (loop header, link,
+        // the two chain-end tests) for their slots
+        MI355_UNROLL
+        for (int s = 0; s < U; s++) {
+            const bool done = st[s] == PARK && !ext[s];
+            const bool up = done && len[s] > best[s];
+            best[s] = up ? len[s] : best[s];
+            bestd[s] = up ? p[s] - cand[s] : bestd[s];
+            rv[s] = w.load32((p[s] == NO_POS ? 0u : p[s]) + best[s] - 1);
         }
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            upd[s] = st[s] == PARK && !ext[s] && len[s] > best[s];  // matching.rs:149-151
-            if (upd[s]) {
-                best[s] = len[s];
-                bestd[s] = p[s] - cand[s];
-                if (len[s] != maxlen[s]) rv[s] = w.load32(p[s] + best[s] - 1);
+            const bool done = st[s] == PARK && !ext[s];
+            const bool full = done && best[s] == maxlen[s] && bestd[s] == p[s] - cand[s];  // this compare hit max_length
+            probe[s] = done ? (rv[s] & 0xffffu) : probe[s];
+            const bool more = done && !full && it[s] < checks;
+            if (HAS_Q) {
+                const bool cap = more && !hq[s] && it[s] == checks_q;
+                mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
+                hq[s] = hq[s] || cap;
             }
+            const uint32_t c = cand[s] - dsave[s];
+            const bool go = more && p[s] - c <= (uint32_t)WINDOW_SIZE;  // dsave == 0xFFFF ("none") fails here
+            cand[s] = go ? c : cand[s];
+            it[s] += go ? 1u : 0u;
+            st[s] = done ? (go ? (uint32_t)WALK : (uint32_t)FIN) : st[s];
+            len[s] = done ? 0u : len[s];  // the next compare of this slot starts from byte 0 again
         }
+        // (3) finished slots report and take one new position each; a position without a candidate is
+        // set up as finished (result 0) and reported at the next service
         MI355_UNROLL
-        for (int s = 0; s < U; s++)
-            if (st[s] == PARK && !ext[s]) {
-                if (upd[s] && len[s] == maxlen[s]) {
-                    st[s] = FIN;  // matching.rs:152-156
-                } else {
-                    if (upd[s]) probe[s] = rv[s] & 0xffffu;
-                    follow(s, dsave[s]);
+        for (int s = 0; s < U; s++) {
+            const bool fin = st[s] == FIN;
+            uint32_t idx = NO_POS;
+            if (fin) {
+                if (p[s] != NO_POS) {
+                    uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
+                    emit(p[s], m, (HAS_Q && hq[s]) ? mq[s] : m);
                 }
-                len[s] = 0;  // the next compare of this slot starts from byte 0 again
+                idx = next();
             }
-        // ---- service: finished slots report and take new positions ----
-        MI355_UNROLL
-        for (int s = 0; s < U; s++)
-            if (st[s] == FIN) retire(s);
+            const bool have = idx != NO_POS;
+            const uint32_t ix = have ? idx : 0u;
+            const uint32_t nrel = lim(ix);
+            const bool inr = have && ix < nrel;
+            const bool search = inr && ix + 2 < nrel;  // else no hash byte: never searched (lz77.rs:294-301)
+            const uint32_t p0 = w.load32(ix);
+            const uint32_t d = w.link_far(ix);
+            const bool ok = search && checks > 0 && d <= (uint32_t)WINDOW_SIZE;
+            if (HAS_Q) {
+                const bool cap = ok && checks_q == 0;
+                mq[s] = fin ? 0u : mq[s];
+                hq[s] = fin ? (!HAS_Q || cap) : hq[s];
+            } else {
+                hq[s] = true;
+            }
+            p[s] = fin ? (inr ? ix : (uint32_t)NO_POS) : p[s];
+            cand[s] = fin ? (ok ? ix - d : ix) : cand[s];
+            best[s] = fin ? 1u : best[s];
+            bestd[s] = fin ? 0u : bestd[s];
+            probe[s] = fin ? (p0 & 0xffffu) : probe[s];  // bytes 0,1 of P (matching.rs:110,141)
+            it[s] = fin ? (ok ? 1u : 0u) : it[s];
+            const uint32_t left = nrel - ix;
+            maxlen[s] = fin ? (search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u) : maxlen[s];
+            len[s] = fin ? 0u : len[s];
+            st[s] = fin ? (ok ? (uint32_t)WALK : (have ? (uint32_t)FIN : (uint32_t)IDLE)) : st[s];
+        }
     }
     MI355_STAT_FLUSH(policy)
 #undef MI355_UNROLL
