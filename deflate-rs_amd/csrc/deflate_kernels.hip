@@ -50,7 +50,7 @@ struct LdsWin {  // the window of k_match: bytes and links in one window coordin
     __device__ uint32_t load32(uint32_t i) const {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(by) + (i >> 2);
         uint32_t lo = w[0], hi = w[1];
-        return __builtin_amdgcn_alignbyte(hi, lo, i & 3);
+        return __builtin_amdgcn_alignbyte(hi, lo, i);  // v_alignbyte_b32 shifts by bits 1:0 of i
     }
     // the window keeps "no earlier position" as 0xFFFF (k_match converts while staging), so the
     // common step needs no separate test for it
@@ -294,8 +294,11 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
                                                     const uint16_t* __restrict__ link, uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
                                                     int in_aligned4, SegEnds sg) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[MW_BYTES];
-    __shared__ __attribute__((aligned(16))) uint16_t s_link[MW_LINKS];
+    // one block, bytes first: both arrays then start below 64 KiB and their base folds into the
+    // 16-bit offset field of the ds_read instructions
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[MW_BYTES + 2 * MW_LINKS];
+    uint8_t* const s_bytes = s_win;
+    uint16_t* const s_link = reinterpret_cast<uint16_t*>(s_win + MW_BYTES);
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x;
     const uint64_t E = (uint64_t)blockIdx.x * MT;
