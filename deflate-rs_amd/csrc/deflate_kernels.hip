@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in,
 // their batch).  Per group of LG batches the table traffic is issued back to back in batch order --
 // read(g), write(g), read(g+1), ...: the LDS executes one wave's operations in order, so read(g+1)
 // sees write(g), the writes do not depend on the reads, and the wave waits once per group.
-constexpr int LG = 8;
+#ifndef MI355_LINKS_LG
+#define MI355_LINKS_LG 8
+#endif
+constexpr int LG = MI355_LINKS_LG;
 
 //
 // `ident`: the reference's head table starts as head[h] = h (chained_hash_table.rs:64-69), so until
@@ -156,41 +159,68 @@ __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict
                                                 const uint16_t* __restrict__ hl, uint32_t ident) {
     __shared__ uint16_t head[32768];
     const uint32_t lane = threadIdx.x;
-    const uint64_t c0 = (uint64_t)blockIdx.x * WINDOW_SIZE;
-    const int64_t base = (int64_t)c0 - WINDOW_SIZE;  // window-relative 0
+    const uint32_t c0 = blockIdx.x * (uint32_t)WINDOW_SIZE;
+    const uint32_t start = c0 >= (uint32_t)WINDOW_SIZE ? c0 - WINDOW_SIZE : 0;
+    const uint32_t bias = c0 >= (uint32_t)WINDOW_SIZE ? 0 : WINDOW_SIZE;  // table value of position p: p - start + bias
     const bool id = ident && blockIdx.x < 2;
-    for (uint32_t i = lane; i < 32768; i += 64) head[i] = id ? (uint16_t)((int64_t)i - base) : (uint16_t)0xFFFF;
+    for (uint32_t i = lane; i < 32768; i += 64) head[i] = id ? (uint16_t)(i - start + bias) : (uint16_t)0xFFFF;
     __syncthreads();
-    uint64_t start = base < 0 ? 0 : (uint64_t)base;
-    uint64_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;
-    const uint64_t nclamp = n - 1;
-    uint32_t chl[LG], clk[LG], nhl[LG], nlk[LG];
+    const uint32_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;
+    // One wave, nothing else on its SIMD: every instruction counts.  Both arrays are padded by
+    // LINKS_PAD entries, so the loads need no clamp, and they are addressed as base + 32-bit index.
+    // hl/link of the groups one and two ahead are in flight while a group is worked on.
+    const uint16_t* hls = hl + start;
+    uint16_t* lks = link + start;
+    const uint32_t count = stop - start;
+    const uint32_t own = c0 - start;  // the previous epoch comes first: it only warms the table
+    uint32_t chl[LG], nhl[LG], fhl[LG];
 #pragma unroll
     for (int g = 0; g < LG; g++) {
-        uint64_t p = start + 64 * g + lane;
-        uint64_t q = p < n ? p : nclamp;
-        chl[g] = hl[q];
-        clk[g] = link[q];
+        const uint32_t i = 64 * g + lane;
+        chl[g] = hls[i];
+        nhl[g] = hls[i + 64 * LG];
     }
-    for (uint64_t p0 = start; p0 < stop; p0 += 64 * LG) {
+    for (uint32_t i0 = 0; i0 < own; i0 += 64 * LG) {  // (epochs are multiples of 64 * LG)
+#pragma unroll
+        for (int g = 0; g < LG; g++) fhl[g] = hls[i0 + 64 * (2 * LG + g) + lane];
+        wave_lds_fence();
 #pragma unroll
         for (int g = 0; g < LG; g++) {
-            uint64_t p = p0 + 64 * (LG + g) + lane;
-            uint64_t q = p < n ? p : nclamp;
-            nhl[g] = hl[q];
-            nlk[g] = link[q];
+            const uint32_t i = i0 + 64 * g + lane;
+            if (chl[g] >> 15) head[chl[g] & 0x7fff] = (uint16_t)(i + bias);  // (start + i + 2 < n holds before c0 <= n)
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            chl[g] = nhl[g];
+            nhl[g] = fhl[g];
+        }
+    }
+    uint32_t clk[LG], nlk[LG], flk[LG];
+#pragma unroll
+    for (int g = 0; g < LG; g++) {
+        const uint32_t i = own + 64 * g + lane;
+        clk[g] = lks[i];
+        nlk[g] = lks[i + 64 * LG];
+    }
+    for (uint32_t i0 = own; i0 < count; i0 += 64 * LG) {
+#pragma unroll
+        for (int g = 0; g < LG; g++) {
+            const uint32_t i = i0 + 64 * (2 * LG + g) + lane;
+            fhl[g] = hls[i];
+            flk[g] = lks[i];
         }
         uint32_t stored[LG], rel[LG];
         bool need[LG];
         wave_lds_fence();
 #pragma unroll
         for (int g = 0; g < LG; g++) {
-            uint64_t p = p0 + 64 * g + lane;
-            bool active = p + 2 < n && p < stop;
-            uint32_t h = chl[g] & 0x7fff;
-            rel[g] = (uint32_t)((int64_t)p - base);  // 0..65535
+            const uint32_t i = i0 + 64 * g + lane;
+            const bool active = start + i + 2 < n && i < count;
+            const uint32_t h = chl[g] & 0x7fff;
+            rel[g] = i + bias;  // 0..65535
             need[g] = active && clk[g] == 0;
-            bool last = active && (chl[g] >> 15);
+            const bool last = active && (chl[g] >> 15);
             stored[g] = need[g] ? (uint32_t)head[h] : 0xFFFFu;
             wave_lds_fence();
             if (last) head[h] = (uint16_t)rel[g];
@@ -198,17 +228,19 @@ __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict
         }
 #pragma unroll
         for (int g = 0; g < LG; g++) {
-            uint64_t p = p0 + 64 * g + lane;
-            if (need[g] && p >= c0 && stored[g] < rel[g] && rel[g] - stored[g] <= WINDOW_SIZE)
-                link[p] = (uint16_t)(rel[g] - stored[g]);
+            const uint32_t i = i0 + 64 * g + lane;
+            if (need[g] && stored[g] < rel[g] && rel[g] - stored[g] <= WINDOW_SIZE) lks[i] = (uint16_t)(rel[g] - stored[g]);
         }
 #pragma unroll
         for (int g = 0; g < LG; g++) {
             chl[g] = nhl[g];
             clk[g] = nlk[g];
+            nhl[g] = fhl[g];
+            nlk[g] = flk[g];
         }
     }
 }
+constexpr uint32_t LINKS_PAD = 64 * 3 * LG + 64;  // what k_links_b reads past the last position
 
 // ---------------------------------------------------------------------------------------------
 // k_match: matching.rs:87-166 longest_match (prev_length = 0) for every position.  A workgroup
