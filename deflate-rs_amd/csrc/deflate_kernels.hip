@@ -634,30 +634,38 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (lane == 0) cnt[k] = running;
 }
 
-// k_scan: exclusive scan of the per-segment token counts (single workgroup).
+// k_scan: exclusive scan of the per-segment token counts (single workgroup).  Each wave owns a
+// contiguous sixteenth and walks it 64 counts at a time (coalesced), scanning in registers; the
+// sixteen totals are scanned through LDS and added in a second walk.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base,
                                                DevScalars* sc) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    uint64_t per = ((uint64_t)K + 1023) / 1024;
-    uint64_t lo = tid * per, hi = lo + per < K ? lo + per : K;
-    uint32_t s = 0;
-    for (uint64_t i = lo; i < hi; i++) s += cnt[i];
-    part[tid] = s;
+    __shared__ uint32_t wtot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t per = ((K + 15) / 16 + 63) / 64 * 64;  // per wave, a multiple of 64
+    const uint32_t lo = wv * per < K ? wv * per : K;
+    const uint32_t hi = lo + per < K ? lo + per : K;
+    uint32_t run = 0;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = i < hi ? cnt[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= (uint32_t)off) x += y;
+        }
+        if (i < hi) base[i] = run + x - v;
+        run += __shfl(x, 63, 64);
+    }
+    if (lane == 0) wtot[wv] = run;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    uint32_t add = 0, T = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        add += k < wv ? wtot[k] : 0;
+        T += wtot[k];
     }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint64_t i = lo; i < hi; i++) {
-        base[i] = run;
-        run += cnt[i];
-    }
-    if (tid == 1023) {
-        uint32_t T = part[1023];
+    for (uint32_t i = lo + lane; i < hi; i += 64) base[i] += add;
+    if (tid == 0) {
         sc->T = T;
         sc->nb = T / MAX_BUFFER_LENGTH + 1;
     }
