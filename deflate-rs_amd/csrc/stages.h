@@ -409,8 +409,8 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             }
             MI355_UNROLL
             for (int s = 0; s < U; s++) {
-                const uint32_t x = ra[s] ^ rb[s], y = ra2[s] ^ rb2[s];
-                const uint32_t n8 = x ? (ctz32(x) >> 3) : (y ? 4u + (ctz32(y) >> 3) : 8u);
+                const uint64_t z = ((uint64_t)(ra2[s] ^ rb2[s]) << 32) | (ra[s] ^ rb[s]);
+                const uint32_t n8 = z ? ((uint32_t)__builtin_ctzll(z) >> 3) : 8u;
                 uint32_t nl = len[s] + n8;
                 nl = nl < maxlen[s] ? nl : maxlen[s];
                 const bool stop = n8 < 8 || nl == maxlen[s];
