@@ -314,7 +314,9 @@ struct WavePolicy {
 struct TileLimit {
     SegEnds sg;
     uint64_t wstart;
+    uint32_t one;  // window-relative end of the input when there are no flush points (read once), else 0
     __device__ uint32_t operator()(uint32_t idx) const {
+        if (sg.m == 1) return one;
         uint64_t e = seg_end(sg, wstart + idx);
         uint64_t r = e - wstart;
         return r > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
 #else
     WavePolicy pol;
 #endif
-    TileLimit lim{sg, wstart};
+    TileLimit lim{sg, wstart, sg.m == 1 ? (uint32_t)(sg.ends[0] - wstart) : 0u};
     match_walk_park<MCHAINS, HAS_Q>(win, next, lim, checks, checks_q, emit, pol);
 #ifdef MI355_MATCH_STATS
     __syncthreads();
