@@ -81,7 +81,8 @@ struct DevScalars {
     uint32_t ref_panic;
     uint32_t n_stored, n_fixed, n_dynamic;
     uint32_t adler;
-    uint32_t pad;
+    uint32_t crc;          // CRC-32 of the input (gzip trailer), XOR-accumulated by k_crc_fold
+    uint64_t adler_a, adler_b;  // sums of the chunk contributions (k_adler_part)
 };
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
@@ -1276,47 +1277,68 @@ __global__ __launch_bounds__(256) void k_shard_costs(const BlockHeader* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Adler-32 (RFC 1950; crate adler32 as used by checksum.rs:33-57): per-chunk (a, b) partials,
-// then one lane folds them: a' = a + a_c, b' = b + len_c * a + b_c (mod 65521).
+// Adler-32 (RFC 1950; crate adler32 as used by checksum.rs:33-57).  With a = 1 + sum d_j and
+// b = n + sum (n - j) d_j, a 16 KiB chunk c contributes a_c = sum d and b_c + after_c * a_c, where
+// b_c = sum (len_c - k) d_k inside the chunk and after_c = bytes behind it: no order between chunks,
+// so every workgroup adds its two numbers (reduced mod 65521) into 64-bit sums and one lane
+// finishes.  A thread takes 16-byte pieces (coalesced): piece at chunk offset o gives s = sum d,
+// w = sum k d_k, and (len - o) s - w to b.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t ADLER_CHUNK = 4096;
-__global__ __launch_bounds__(256) void k_adler_part(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ pa,
-                                                    uint32_t* __restrict__ pb) {
-    __shared__ uint32_t sa[256], sb[256];
-    uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
-    uint32_t len = n - c0 < ADLER_CHUNK ? (uint32_t)(n - c0) : ADLER_CHUNK;
+constexpr uint32_t ADLER_CHUNK = 16384;
+__global__ __launch_bounds__(256) void k_adler_part(const uint8_t* __restrict__ in, uint32_t n, DevScalars* sc) {
+    __shared__ uint32_t sa[4], sb[4];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
+    const uint32_t len = n - c0 < ADLER_CHUNK ? (uint32_t)(n - c0) : ADLER_CHUNK;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     uint32_t a = 0, b = 0;
-    // b part of byte i (0-based in the chunk) is (len - i) * d
-    for (uint32_t i = threadIdx.x; i < len; i += 256) {
-        uint32_t d = in[c0 + i];
-        a += d;
-        b += (len - i) * d;  // <= 16 * 4096 * 255 < 2^32
-    }
-    sa[threadIdx.x] = a;
-    sb[threadIdx.x] = b % 65521u;
-    __syncthreads();
-    for (uint32_t off = 128; off; off >>= 1) {
-        if (threadIdx.x < off) {
-            sa[threadIdx.x] += sa[threadIdx.x + off];
-            sb[threadIdx.x] = (sb[threadIdx.x] + sb[threadIdx.x + off]) % 65521u;
+#pragma unroll
+    for (uint32_t i = 0; i < ADLER_CHUNK / (256 * 16); i++) {
+        const uint32_t o = (i * 256 + tid) * 16;
+        if (o >= len) break;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (o + 16 <= len && aligned) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + c0 + o);
+            v[0] = q.x;
+            v[1] = q.y;
+            v[2] = q.z;
+            v[3] = q.w;
+        } else {
+            for (uint32_t k = 0; k < 16; k++)
+                if (o + k < len) v[k >> 2] |= (uint32_t)in[c0 + o + k] << (8 * (k & 3));
         }
-        __syncthreads();
+        uint32_t s = 0, w = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t d = (v[k >> 2] >> (8 * (k & 3))) & 0xff;  // (bytes past the end are 0)
+            s += d;
+            w += k * d;
+        }
+        a += s;
+        b += (len - o) * s - w;  // <= 4 * 16384 * 4080 < 2^32
     }
-    if (threadIdx.x == 0) {
-        pa[blockIdx.x] = sa[0] % 65521u;
-        pb[blockIdx.x] = sb[0];
+    b %= 65521u;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        sa[tid >> 6] = a;
+        sb[tid >> 6] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint64_t A = ((uint64_t)sa[0] + sa[1] + sa[2] + sa[3]) % 65521u;
+        const uint64_t B = ((uint64_t)sb[0] + sb[1] + sb[2] + sb[3]) % 65521u;
+        const uint64_t after = (uint64_t)n - c0 - len;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sc->adler_a), (unsigned long long)A);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sc->adler_b), (unsigned long long)((B + (after % 65521u) * A) % 65521u));
     }
 }
-__global__ void k_adler_fold(uint32_t n, uint32_t nchunks, const uint32_t* __restrict__ pa,
-                             const uint32_t* __restrict__ pb, DevScalars* sc) {
+__global__ void k_adler_fold(uint32_t n, DevScalars* sc) {
     if (threadIdx.x || blockIdx.x) return;
-    uint64_t a = 1, b = 0;
-    for (uint32_t c = 0; c < nchunks; c++) {
-        uint64_t c0 = (uint64_t)c * ADLER_CHUNK;
-        uint64_t len = n - c0 < ADLER_CHUNK ? n - c0 : ADLER_CHUNK;
-        b = (b + len * a + pb[c]) % 65521u;
-        a = (a + pa[c]) % 65521u;
-    }
+    const uint64_t a = (1 + sc->adler_a) % 65521u, b = (n + sc->adler_b) % 65521u;
     sc->adler = (uint32_t)((b << 16) | a);
 }
 
@@ -1332,6 +1354,133 @@ __global__ void k_zlib_frame(DevScalars* sc, uint8_t* out, uint32_t trailer) {
     out[2 + nbytes + 1] = (uint8_t)(a >> 16);
     out[2 + nbytes + 2] = (uint8_t)(a >> 8);
     out[2 + nbytes + 3] = (uint8_t)a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CRC-32 (RFC 1952 section 8; crate gzip-header 1.0 `Crc`, as used by lib.rs:258-266 and
+// writer.rs:408-444).  k_crc_part: every thread runs the table-driven CRC (four bytes per step, four
+// 256-entry tables in LDS) over its own 512-byte chunk; the chunks of a workgroup are staged through
+// LDS in 128-byte pieces so that eight lanes read one full 128-byte line of HBM and a thread then
+// reads its piece bank-conflict free (row stride 33 words).  k_crc_fold: CRCs are linear in the
+// sense of zlib's crc32_combine, crc(A||B) = x^(8|B|) * crc(A) + crc(B) over GF(2)[x] mod P, so
+// crc(input) = sum_i x^(8 * bytes after chunk i) * crc(chunk_i): every thread raises its own factor
+// by squaring and the products are XOR-ed together.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t CRC_CHUNK = 512;   // bytes per thread
+constexpr uint32_t CRC_PIECE = 128;   // bytes per thread per staging round
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+
+// a(x) * b(x) mod P, reflected representation (bit 31 = x^0)
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+    }
+    return p;
+}
+// x^(8 * nbytes) mod P
+__device__ uint32_t crc_xpow8(uint64_t nbytes) {
+    uint32_t r = 0x80000000u;  // x^0
+    uint32_t sq = 0x00800000u; // x^8
+    while (nbytes) {
+        if (nbytes & 1) r = crc_mulmod(sq, r);
+        sq = crc_mulmod(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_crc_part(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ part) {
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t stage[256 * 33];
+    const uint32_t tid = threadIdx.x;
+    {
+        uint32_t c = tid;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        T[0][tid] = c;
+    }
+    __syncthreads();
+    for (int t = 1; t < 4; t++) {
+        uint32_t v = T[t - 1][tid];
+        T[t][tid] = (v >> 8) ^ T[0][v & 0xff];
+        __syncthreads();
+    }
+    const uint64_t tile = (uint64_t)blockIdx.x * 256 * CRC_CHUNK;
+    const uint64_t my0 = tile + (uint64_t)tid * CRC_CHUNK;
+    const uint32_t mylen = my0 >= n ? 0u : (n - my0 < CRC_CHUNK ? (uint32_t)(n - my0) : CRC_CHUNK);
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    uint32_t crc = 0xFFFFFFFFu;
+    for (uint32_t piece = 0; piece < CRC_CHUNK / CRC_PIECE; piece++) {
+        // stage: lane j of round r loads 16 bytes of chunk (r * 32 + j / 8), part j % 8
+        for (uint32_t r = 0; r < 8; r++) {
+            const uint32_t c = r * 32 + tid / 8, part16 = tid % 8;
+            const uint64_t g = tile + (uint64_t)c * CRC_CHUNK + piece * CRC_PIECE + part16 * 16;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (g + 16 <= n && aligned) {
+                const uint4 q = *reinterpret_cast<const uint4*>(in + g);
+                v[0] = q.x;
+                v[1] = q.y;
+                v[2] = q.z;
+                v[3] = q.w;
+            } else {
+                for (uint32_t b = 0; b < 16; b++)
+                    if (g + b < n) v[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
+            }
+            uint32_t* dst = stage + c * 33 + part16 * 4;
+            dst[0] = v[0];
+            dst[1] = v[1];
+            dst[2] = v[2];
+            dst[3] = v[3];
+        }
+        __syncthreads();
+        const uint32_t done = piece * CRC_PIECE;
+        const uint32_t here = mylen > done ? (mylen - done < CRC_PIECE ? mylen - done : CRC_PIECE) : 0u;
+        const uint32_t* src = stage + tid * 33;
+        uint32_t w = 0;
+        for (; w * 4 + 4 <= here; w++) {
+            crc ^= src[w];
+            crc = T[3][crc & 0xff] ^ T[2][(crc >> 8) & 0xff] ^ T[1][(crc >> 16) & 0xff] ^ T[0][crc >> 24];
+        }
+        for (uint32_t b = w * 4; b < here; b++) {
+            const uint32_t d = (src[b >> 2] >> (8 * (b & 3))) & 0xff;
+            crc = T[0][(crc ^ d) & 0xff] ^ (crc >> 8);
+        }
+        __syncthreads();
+    }
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + tid;
+    if (mylen) part[idx] = ~crc;
+}
+
+__global__ __launch_bounds__(256) void k_crc_fold(uint32_t n, uint32_t nchunks, const uint32_t* __restrict__ part,
+                                                  DevScalars* sc) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = 0;
+    if (i < nchunks) {
+        const uint64_t end = (uint64_t)(i + 1) * CRC_CHUNK;
+        const uint64_t after = end < n ? n - end : 0;
+        v = part[i];
+        if (after) v = crc_mulmod(crc_xpow8(after), v);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v ^= __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicXor(&sc->crc, v);
+}
+
+// gzip framing written on the device (lib.rs:250-266): the caller's header bytes, then after the
+// stream CRC-32 and the input length mod 2^32, both little endian.
+__global__ void k_gzip_frame(DevScalars* sc, uint8_t* out, const uint8_t* hdr, uint32_t hdr_len, uint32_t in_len,
+                             uint32_t trailer) {
+    if (blockIdx.x) return;
+    for (uint32_t i = threadIdx.x; i < hdr_len; i += blockDim.x) out[i] = hdr[i];
+    if (threadIdx.x || !trailer) return;
+    uint64_t nbytes = (sc->total_bits + 7) / 8;
+    uint8_t* t = out + hdr_len + nbytes;
+    uint32_t c = sc->crc;
+    for (int k = 0; k < 4; k++) t[k] = (uint8_t)(c >> (8 * k));
+    for (int k = 0; k < 4; k++) t[4 + k] = (uint8_t)(in_len >> (8 * k));
 }
 
 }  // namespace mi355

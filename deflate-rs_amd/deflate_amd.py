@@ -145,6 +145,14 @@ def load():
     L.mi355_shard_end.argtypes = [C.c_void_p]
     L.mi355_shard_end.restype = None
     L.mi355_adler32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
+    L.mi355_crc32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
+    L.mi355_deflate_encode_gzip.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t,
+                                            u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_deflate_encode_device_gzip.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Opts), C.c_char_p,
+                                                   C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                                   C.c_void_p]
+    L.mi355_deflate_stream_gzip_header.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mi355_deflate_stream_reset.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t)]
     L.mi355_deflate_stream_new.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
     L.mi355_deflate_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.mi355_deflate_stream_flush.argtypes = [C.c_void_p]
@@ -164,6 +172,8 @@ EXPORTED = [
     "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_flush",
     "mi355_deflate_stream_finish",
     "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
+    "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset", "mi355_deflate_encode_gzip",
+    "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
     "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end",
 ]
@@ -208,6 +218,28 @@ class Context:
         if rc != OK:
             self._err(rc)
         return bytes(memoryview(out)[: n.value])
+
+    def encode_gzip(self, data, options=Compression.Default, header=None, compat=0):
+        """mi355_deflate_encode_gzip; header = GzBuilder::into_header() bytes (None: the blank one)."""
+        L = load()
+        o = CompressionOptions.from_(options).to_c(2, compat, 0)
+        data = bytes(data)
+        header = BLANK_GZIP_HEADER if header is None else bytes(header)
+        cap = L.mi355_deflate_bound(len(data)) + 32 + len(header)
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_encode_gzip(self._h, data, len(data), C.byref(o), header, len(header), out, cap,
+                                         C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return bytes(memoryview(out)[: n.value])
+
+    def crc32_device(self, d_ptr, n, stream=0):
+        a = C.c_uint32(0)
+        rc = load().mi355_crc32_device(self._h, C.c_void_p(d_ptr), n, C.byref(a), C.c_void_p(stream))
+        if rc != OK:
+            self._err(rc)
+        return a.value
 
     def encode_device(self, d_in_ptr, in_len, d_out_ptr, out_cap, options=Compression.Default, wrapper=0,
                       compat=0, stream=0, flush=0):
@@ -283,6 +315,33 @@ def deflate_bytes_zlib(data, ctx=None):
     return deflate_bytes_zlib_conf(data, Compression.Default, ctx)
 
 
+# GzBuilder::new().into_header() of crate gzip-header 1.0 (the crate is not in the reference tree)
+BLANK_GZIP_HEADER = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff])
+
+
+def gzip_header(filename=None, comment=None, extra=None, mtime=0, xfl=0, os_code=255):
+    """RFC 1952 member header as GzBuilder builds it (fields in the order FEXTRA, FNAME, FCOMMENT)."""
+    flg = (4 if extra is not None else 0) | (8 if filename is not None else 0) | (16 if comment is not None else 0)
+    h = bytearray([0x1f, 0x8b, 8, flg]) + int(mtime).to_bytes(4, "little") + bytes([xfl, os_code])
+    if extra is not None:
+        h += len(extra).to_bytes(2, "little") + bytes(extra)
+    if filename is not None:
+        h += bytes(filename) + b"\0"
+    if comment is not None:
+        h += bytes(comment) + b"\0"
+    return bytes(h)
+
+
+def deflate_bytes_gzip_conf(data, options, header=None, ctx=None):
+    """src/lib.rs:242-267 (feature "gzip"); header = GzBuilder::into_header() bytes"""
+    return (ctx or default_context()).encode_gzip(data, options, header)
+
+
+def deflate_bytes_gzip(data, ctx=None):
+    """src/lib.rs:283-285"""
+    return deflate_bytes_gzip_conf(data, Compression.Default, None, ctx)
+
+
 # ---- the reference's Write encoders (src/writer.rs) ---------------------------------------------
 class _Encoder:
     _wrapper = 0
@@ -326,6 +385,27 @@ class _Encoder:
         self._w.write(C.string_at(p, n.value) if n.value else b"")
         return self._w
 
+    def reset(self, writer):
+        """reset(&mut self, W) -> W (writer.rs:110-117, 216-223, 383-402): the finished stream goes to the
+        old writer, which is returned; the encoder starts over on `writer` with the same options"""
+        L = load()
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_stream_reset(self._s, C.byref(p), C.byref(n))
+        if rc != OK:
+            raise DeflateError(rc, L.mi355_deflate_last_error(self._ctx._h).decode())
+        self._w.write(C.string_at(p, n.value) if n.value else b"")
+        old, self._w = self._w, writer
+        return old
+
+    def checksum(self):
+        """{Zlib,Gz}Encoder::checksum() (writer.rs:248-250, :428-430)"""
+        a = C.c_uint32(0)
+        rc = load().mi355_deflate_stream_checksum(self._s, C.byref(a))
+        if rc != OK:
+            raise DeflateError(rc, "stream_checksum")
+        return a.value
+
     def __del__(self):
         if getattr(self, "_s", None):
             try:
@@ -344,13 +424,29 @@ class ZlibEncoder(_Encoder):
     """write::ZlibEncoder (src/writer.rs:183-290)"""
     _wrapper = 1
 
-    def checksum(self):
-        """src/writer.rs:248-250"""
-        a = C.c_uint32(0)
-        rc = load().mi355_deflate_stream_checksum(self._s, C.byref(a))
+
+class GzEncoder(_Encoder):
+    """write::gzip::GzEncoder (src/writer.rs:293-467, feature "gzip")"""
+    _wrapper = 2
+
+    @classmethod
+    def from_builder(cls, header, writer, options=Compression.Default, ctx=None):
+        """from_builder(builder, writer, options) (:346-358); header = builder.into_header() bytes"""
+        e = cls(writer, options, ctx)
+        e.set_header(header)
+        return e
+
+    def set_header(self, header):
+        header = bytes(header)
+        rc = load().mi355_deflate_stream_gzip_header(self._s, header, len(header))
         if rc != OK:
-            raise DeflateError(rc, "stream_checksum")
-        return a.value
+            raise DeflateError(rc, "stream_gzip_header")
+
+    def reset_with_builder(self, writer, header):
+        """reset_with_builder (:393-402)"""
+        old = self.reset(writer)
+        self.set_header(header)
+        return old
 
 
 # ---- sharded, stream-exact encode: the per-rank phases (mi355_shard_*) -------------------------------

@@ -43,7 +43,11 @@ typedef struct {
     uint8_t matching_type;      /* 0 = MatchingType::Greedy, 1 = MatchingType::Lazy */
     uint8_t wrapper;            /* 0 = raw deflate (deflate_bytes_conf, DeflateEncoder),
                                    1 = zlib: 78 9C + Adler-32 BE (deflate_bytes_zlib_conf,
-                                   ZlibEncoder; src/lib.rs:182-198, src/zlib.rs:59-62) */
+                                   ZlibEncoder; src/lib.rs:182-198, src/zlib.rs:59-62),
+                                   2 = gzip: header + CRC-32 LE + length mod 2^32 LE (feature "gzip":
+                                   deflate_bytes_gzip_conf src/lib.rs:242-267, GzEncoder
+                                   src/writer.rs:293-467); the header is GzBuilder::new()'s unless
+                                   one of the _gzip entry points supplies it */
     uint8_t compat;             /* MI355_COMPAT_* bits */
     uint8_t flush;              /* MI355_FLUSH_FINISH (0) or MI355_FLUSH_SYNC (1) */
 } mi355_deflate_opts;
@@ -173,6 +177,21 @@ int mi355_shard_pack(mi355_shard* s, const mi355_block_info* plans, uint64_t end
                      uint64_t* first_byte, size_t* n_bytes);
 void mi355_shard_end(mi355_shard* s);
 
+/* The gzip forms (cargo feature "gzip").  `hdr` = the bytes GzBuilder::into_header() returned: the
+ * header comes from the crate gzip-header 1.0, which is not part of the reference tree, so the shim
+ * builds it with the real crate and passes it through.  Written after the stream: Crc::sum() and
+ * Crc::amt_as_u32() little endian (src/lib.rs:258-266), both computed on the GPU.
+ *   mi355_deflate_encode_gzip        = deflate_bytes_gzip_conf(input, options, builder)  :242-267
+ *   mi355_deflate_encode with wrapper 2 = deflate_bytes_gzip(input) (blank header)        :283-285 */
+int mi355_deflate_encode_gzip(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
+                              const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_cap, size_t* out_len);
+int mi355_deflate_encode_device_gzip(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len,
+                                     const mi355_deflate_opts* opts, const uint8_t* hdr, size_t hdr_len, void* d_out,
+                                     size_t out_cap, size_t* out_len, void* hip_stream);
+/* CRC-32 (RFC 1952 section 8) of a device buffer: gzip_header::Crc::update + sum as used by
+ * src/lib.rs:258-259 and src/writer.rs:436-444, computed on the GPU. */
+int mi355_crc32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, uint32_t* crc, void* hip_stream);
+
 /* Adler-32 of a device buffer (crate adler32's RollingAdler32::update_buffer as used by
  * src/checksum.rs:33-57), computed on the GPU. */
 int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, uint32_t* adler, void* hip_stream);
@@ -188,7 +207,7 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  * gathered and encoded on the GPU at finish().  One _write call stands for one write_all call
  * (n == 0: no call at all); the size of the first write after a flush is remembered, because the
  * reference's hash re-warm at a flush point inside the first window depends on it
- * (src/lz77.rs:601-638).  reset() is not implemented in this round. */
+ * (src/lz77.rs:601-638).  */
 typedef struct mi355_deflate_stream mi355_deflate_stream;
 int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* opts, mi355_deflate_stream** out);
 int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);
@@ -198,6 +217,13 @@ int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, siz
  * MI355_E_UNSUPPORTED: a flush after only 1-2 bytes, and a 1-byte write right after a flush. */
 int mi355_deflate_stream_flush(mi355_deflate_stream* s);
 int mi355_deflate_stream_finish(mi355_deflate_stream* s);
+/* GzEncoder::from_builder (src/writer.rs:346-358): header bytes of a wrapper-2 stream, before the first
+ * write; _checksum of such a stream is GzEncoder::checksum() (:428-430), the CRC-32. */
+int mi355_deflate_stream_gzip_header(mi355_deflate_stream* s, const uint8_t* hdr, size_t hdr_len);
+/* reset(&mut self, W) -> io::Result<W> (src/writer.rs:110-117, 216-223, 383-402): finishes the stream,
+ * hands its bytes out (valid until the next reset / free) and starts a new one with the same options
+ * (gzip: with the blank header again, as GzEncoder::reset does). */
+int mi355_deflate_stream_reset(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
 int mi355_deflate_stream_output(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
 int mi355_deflate_stream_checksum(mi355_deflate_stream* s, uint32_t* adler);
 void mi355_deflate_stream_free(mi355_deflate_stream* s);

@@ -1495,6 +1495,16 @@ u32 adler32_update(u32 adler, const u8* data, size_t n) {
     return (b << 16) | a;
 }
 
+/* crate gzip-header 1.0 `Crc` (a wrapper of crc32fast): RFC 1952 section 8, bit by bit */
+u32 crc32_update(u32 crc, const u8* data, size_t n) {
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) {
+        crc ^= data[i];
+        for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+
 } // namespace
 
 /* ==========================================================================================
@@ -1505,14 +1515,33 @@ struct deflref_stream {
     Sink sink;
     DeflateState* ds;
     u32 adler = 1;
+    u32 crc = 0;      /* gzip: Crc::sum() */
+    u32 amount = 0;   /* gzip: Crc::amt_as_u32() */
+    std::vector<u8> gz_header;
+    std::vector<u8> handed_out; /* what reset() returned */
     bool header_written = false;
     bool finished = false;
-    void check_write_header() { /* writer.rs:226-232 */
+    void check_write_header() { /* writer.rs:226-232 (zlib), :360-368 (gzip) */
         if (opts.wrapper == 1 && !header_written) {
             u8 h[2];
             get_zlib_header(2 << 6, h);
             ds->output_buf().insert(ds->output_buf().end(), h, h + 2);
             header_written = true;
+        }
+        if (opts.wrapper == 2 && !gz_header.empty()) {
+            ds->output_buf().insert(ds->output_buf().end(), gz_header.begin(), gz_header.end());
+            gz_header.clear();
+        }
+    }
+    void write_trailer() { /* writer.rs:235-245 (zlib), :408-425 (gzip) */
+        if (opts.wrapper == 1) {
+            u8 t[4] = {(u8)(adler >> 24), (u8)(adler >> 16), (u8)(adler >> 8), (u8)adler};
+            sink.write_all(t, 4);
+        }
+        if (opts.wrapper == 2) {
+            u8 t[8] = {(u8)crc, (u8)(crc >> 8), (u8)(crc >> 16), (u8)(crc >> 24),
+                       (u8)amount, (u8)(amount >> 8), (u8)(amount >> 16), (u8)(amount >> 24)};
+            sink.write_all(t, 8);
         }
     }
 };
@@ -1576,6 +1605,36 @@ int deflref_encode(const uint8_t* in, size_t in_len, const deflref_opts* opts, u
     GUARD_END
 }
 
+uint32_t deflref_crc32(uint32_t crc, const uint8_t* data, size_t n) { return crc32_update(crc, data, n); }
+
+int deflref_encode_gzip(const uint8_t* in, size_t in_len, const deflref_opts* opts, const uint8_t* hdr,
+                        size_t hdr_len, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!opts || !out_len || (!in && in_len) || (!hdr && hdr_len)) return DEFLREF_E_ARG;
+    g_hazards = 0;
+    g_trace.clear();
+    g_trace_on = true;
+    GUARD_BEGIN
+    Sink sink;
+    sink.write_all(hdr, hdr_len); /* lib.rs:250-253 */
+    {
+        deflref_opts o = *opts;
+        o.wrapper = 0;
+        DeflateState ds(o, &sink); /* :254-256 */
+        compress_until_done(in, in_len, ds, FlushFinish);
+    }
+    u32 crc = crc32_update(0, in, in_len); /* :258-259 */
+    u32 amt = (u32)in_len;
+    u8 t[8] = {(u8)crc, (u8)(crc >> 8), (u8)(crc >> 16), (u8)(crc >> 24),
+               (u8)amt, (u8)(amt >> 8), (u8)(amt >> 16), (u8)(amt >> 24)};
+    sink.write_all(t, 8); /* :261-266 */
+    g_trace_on = false;
+    *out_len = sink.data.size();
+    if (sink.data.size() > out_cap) return DEFLREF_E_OUT_TOO_SMALL;
+    memcpy(out, sink.data.data(), sink.data.size());
+    return DEFLREF_OK;
+    GUARD_END
+}
+
 size_t deflref_trace_blocks(deflref_block_info* out, size_t cap) {
     size_t n = g_trace.size();
     for (size_t i = 0; i < n && i < cap; i++) out[i] = g_trace[i];
@@ -1599,6 +1658,10 @@ int deflref_stream_write(deflref_stream* s, const uint8_t* data, size_t n) {
         if (r.ok) {
             size_t k = r.n == 0 ? n : r.n; /* writer.rs:258-265: Ok(0) checksums the whole buf */
             if (s->opts.wrapper == 1) s->adler = adler32_update(s->adler, data, k);
+            if (s->opts.wrapper == 2) { /* writer.rs:436-444 */
+                s->crc = crc32_update(s->crc, data, k);
+                s->amount += (u32)k;
+            }
             if (r.n == 0) return DEFLREF_E_REF_PANIC; /* write_all -> WriteZero error */
             data += r.n;
             n -= r.n;
@@ -1621,12 +1684,35 @@ int deflref_stream_finish(deflref_stream* s) {
     GUARD_BEGIN
     s->check_write_header(); /* writer.rs:201-205 */
     compress_until_done(nullptr, 0, *s->ds, FlushFinish);
-    if (s->opts.wrapper == 1) {
-        u32 a = s->adler;
-        u8 t[4] = {(u8)(a >> 24), (u8)(a >> 16), (u8)(a >> 8), (u8)a};
-        s->sink.write_all(t, 4);
-    }
+    s->write_trailer();
     s->finished = true;
+    return DEFLREF_OK;
+    GUARD_END
+}
+
+int deflref_stream_gzip_header(deflref_stream* s, const uint8_t* hdr, size_t hdr_len) {
+    if (!s || s->opts.wrapper != 2 || (!hdr && hdr_len)) return DEFLREF_E_ARG;
+    s->gz_header.assign(hdr, hdr + hdr_len);
+    return DEFLREF_OK;
+}
+
+int deflref_stream_reset(deflref_stream* s, const uint8_t** data, size_t* n) {
+    GUARD_BEGIN
+    /* output_all + trailer, then DeflateState::reset with a new Vec (writer.rs:110-117, 216-223,
+     * 383-402; deflate_state.rs:133-152).  The gzip header of the next stream is set again by the
+     * caller (reset uses a blank GzBuilder, reset_with_builder the given one). */
+    s->check_write_header();
+    compress_until_done(nullptr, 0, *s->ds, FlushFinish);
+    s->ds->reset(&s->sink);
+    s->write_trailer();
+    s->handed_out.swap(s->sink.data);
+    s->sink.data.clear();
+    s->adler = 1;
+    s->crc = 0;
+    s->amount = 0;
+    s->header_written = false;
+    if (data) *data = s->handed_out.data();
+    if (n) *n = s->handed_out.size();
     return DEFLREF_OK;
     GUARD_END
 }
@@ -1635,7 +1721,7 @@ size_t deflref_stream_output(deflref_stream* s, const uint8_t** data) {
     *data = s->sink.data.data();
     return s->sink.data.size();
 }
-uint32_t deflref_stream_checksum(deflref_stream* s) { return s->adler; }
+uint32_t deflref_stream_checksum(deflref_stream* s) { return s->opts.wrapper == 2 ? s->crc : s->adler; }
 void deflref_stream_free(deflref_stream* s) {
     if (!s) return;
     delete s->ds;

@@ -31,7 +31,8 @@ typedef struct {
     uint16_t max_hash_checks;
     uint16_t lazy_if_less_than;
     uint8_t matching_type; /* 0 = Greedy, 1 = Lazy */
-    uint8_t wrapper;       /* 0 = raw deflate, 1 = zlib (78 9C + Adler-32 BE) */
+    uint8_t wrapper;       /* 0 = raw deflate, 1 = zlib (78 9C + Adler-32 BE), 2 = gzip (header given by the
+                              caller + CRC-32 LE + length mod 2^32 LE; the streaming form only) */
 } deflref_opts;
 
 /* error codes */
@@ -48,6 +49,14 @@ void deflref_preset(int level, deflref_opts* out);
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-198). */
 int deflref_encode(const uint8_t* in, size_t in_len, const deflref_opts* opts, uint8_t* out,
                    size_t out_cap, size_t* out_len);
+
+/* deflate_bytes_gzip_conf (src/lib.rs:242-267, feature "gzip"): `hdr` = what GzBuilder::into_header()
+ * returned (crate gzip-header 1.0, not in the tree: the header is taken as bytes), then the raw stream,
+ * then Crc::sum() and Crc::amt_as_u32() little endian. */
+int deflref_encode_gzip(const uint8_t* in, size_t in_len, const deflref_opts* opts, const uint8_t* hdr,
+                        size_t hdr_len, uint8_t* out, size_t out_cap, size_t* out_len);
+/* Crc::update / Crc::sum of gzip-header 1.0 = CRC-32 of RFC 1952 section 8 (IEEE 802.3, reflected). */
+uint32_t deflref_crc32(uint32_t crc, const uint8_t* data, size_t n);
 
 /* Worst-case output size for a given input size (stored blocks + framing). */
 size_t deflref_bound(size_t in_len);
@@ -71,6 +80,11 @@ int deflref_stream_finish(deflref_stream* s);
 /* bytes the wrapped Vec<u8> sink holds so far */
 size_t deflref_stream_output(deflref_stream* s, const uint8_t** data);
 uint32_t deflref_stream_checksum(deflref_stream* s);
+/* write::gzip::GzEncoder::from_builder (src/writer.rs:346-358): the header bytes of a wrapper-2 stream */
+int deflref_stream_gzip_header(deflref_stream* s, const uint8_t* hdr, size_t hdr_len);
+/* reset(&mut self, W) (src/writer.rs:110-117, 216-223, 383-402): finishes the stream, hands its bytes
+ * out (valid until the next reset / free) and starts a new one with the same options */
+int deflref_stream_reset(deflref_stream* s, const uint8_t** data, size_t* n);
 void deflref_stream_free(deflref_stream* s);
 
 /* ---- block trace of the last deflref_encode on this thread (for diffing intermediates) ---- */

@@ -116,6 +116,12 @@ def lib():
         L.deflref_rle_chunk.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                         C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]
         L.deflref_rle_chunk.restype = C.c_long
+        L.deflref_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+        L.deflref_crc32.restype = C.c_uint32
+        L.deflref_encode_gzip.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t, u8p,
+                                          C.c_size_t, C.POINTER(C.c_size_t)]
+        L.deflref_stream_gzip_header.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.deflref_stream_reset.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -151,6 +157,26 @@ def encode(data: bytes, opts=None, level=DEFAULT, wrapper=0) -> bytes:
     return bytes(memoryview(out)[: n.value])
 
 
+def encode_gzip(data: bytes, header: bytes, opts=None, level=DEFAULT) -> bytes:
+    """deflate_bytes_gzip_conf (src/lib.rs:242-267); header = GzBuilder::into_header() bytes."""
+    if opts is None:
+        opts = preset(level, 0)
+    L = lib()
+    cap = L.deflref_bound(len(data)) + len(header) + 16
+    out = (C.c_uint8 * cap)()
+    n = C.c_size_t(0)
+    rc = L.deflref_encode_gzip(bytes(data), len(data), C.byref(opts), bytes(header), len(header), out, cap, C.byref(n))
+    if rc == E_REF_PANIC:
+        raise RefPanic(L.deflref_last_panic().decode())
+    if rc != 0:
+        raise RuntimeError("deflref_encode_gzip rc=%d" % rc)
+    return bytes(memoryview(out)[: n.value])
+
+
+def crc32(data: bytes, crc=0) -> int:
+    return lib().deflref_crc32(crc, bytes(data), len(data))
+
+
 def last_hazards():
     return lib().deflref_last_hazards()
 
@@ -182,6 +208,16 @@ class Stream:
 
     def flush(self):
         self._chk(lib().deflref_stream_flush(self._s))
+
+    def gzip_header(self, header: bytes):
+        self._chk(lib().deflref_stream_gzip_header(self._s, bytes(header), len(header)))
+
+    def reset(self) -> bytes:
+        """reset(): the bytes of the stream so far (finished); the encoder starts over"""
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        self._chk(lib().deflref_stream_reset(self._s, C.byref(p), C.byref(n)))
+        return bytes(C.string_at(p, n.value)) if n.value else b""
 
     def finish(self) -> bytes:
         self._chk(lib().deflref_stream_finish(self._s))

@@ -7,6 +7,8 @@ import sys
 import zlib
 
 import pytest
+import torch  # noqa: F401  -- before the library: torch ships its own HIP runtime, and the copy that is loaded
+#                              second in a process does not see the GPU (tests below pass tensors to the C ABI)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -450,3 +452,93 @@ def test_flush_patterns_that_are_refused(da, ctx):
     with pytest.raises(da.DeflateError) as e:
         enc.finish()
     assert e.value.code == da.E_UNSUPPORTED
+
+
+# ---- gzip wrapper, CRC-32 on the GPU (feature "gzip": lib.rs:242-286, writer.rs:293-467) ----
+def test_crc32_device(da, ctx):
+    import torch
+    for n in (0, 1, 3, 4, 5, 15, 16, 17, 511, 512, 513, 131071, 131072, 131073, 1_000_003, 50_000_000):
+        data = datagen.rng_bytes(n, n % 1000 + 1) if n < 2_000_000 else datagen.text_like(n, 5)
+        t = torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert ctx.crc32_device(t.data_ptr(), n) == zlib.crc32(data), n
+    # an unaligned device pointer takes the byte-wise staging path
+    data = datagen.rng_bytes(100003, 9)
+    t = torch.frombuffer(bytearray(b"\0" + data), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert ctx.crc32_device(t.data_ptr() + 1, len(data)) == zlib.crc32(data)
+
+
+def test_gzip_one_shot(da, ctx):
+    import gzip
+    comment = da.gzip_header(comment=b"Comment")
+    for data in (b"", b"a", open(os.path.join(FIX, "pg11.txt"), "rb").read(), datagen.rng_bytes(70000, 3),
+                 datagen.text_like(3_000_000, 8), bytes(70000)):
+        for hdr in (None, comment, da.gzip_header(filename=b"x.txt", extra=b"ab", mtime=12345)):
+            z = da.deflate_bytes_gzip_conf(data, da.Compression.Default, hdr, ctx)
+            assert z == ob.encode_gzip(data, hdr or da.BLANK_GZIP_HEADER, level=ob.DEFAULT)
+            assert gzip.decompress(z) == data
+    assert da.deflate_bytes_gzip(b"This is some test data", ctx) == ob.encode_gzip(b"This is some test data",
+                                                                                   da.BLANK_GZIP_HEADER)
+
+
+# writer.rs:473-491 gzip_writer + flush inside a gzip stream (GzEncoder::flush = inner.flush, :446-455)
+def test_gzip_writer(da, ctx):
+    import gzip
+    import io
+    data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
+    hdr = da.gzip_header(comment=b"Comment")
+    enc = da.GzEncoder.from_builder(hdr, io.BytesIO(), da.CompressionOptions.default(), ctx)
+    ref = ob.Stream(ob.preset(ob.DEFAULT, 2))
+    ref.gzip_header(hdr)
+    for part in (data[:len(data) // 2], data[len(data) // 2:]):
+        enc.write_all(part)
+        ref.write_all(part)
+    assert enc.checksum() == zlib.crc32(data) == ref.checksum()
+    z = enc.finish().getvalue()
+    assert z == ref.finish()
+    assert gzip.decompress(z) == data
+    for cuts in ([40000], [0, 50000]):
+        enc = da.GzEncoder(io.BytesIO(), da.Compression.Default, ctx)
+        ref = ob.Stream(ob.preset(ob.DEFAULT, 2))
+        ref.gzip_header(da.BLANK_GZIP_HEADER)
+        prev = 0
+        for c in cuts:
+            enc.write_all(data[prev:c])
+            ref.write_all(data[prev:c])
+            enc.flush()
+            ref.flush()
+            prev = c
+        enc.write_all(data[prev:])
+        ref.write_all(data[prev:])
+        assert enc.finish().getvalue() == ref.finish()
+
+
+# writer.rs:537-571 writer_reset, writer_reset_zlib (+ gzip): SURVEY section 8 f2 reset()
+def test_reset(da, ctx):
+    import io
+    data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
+    for cls, wrapper in ((da.DeflateEncoder, 0), (da.ZlibEncoder, 1), (da.GzEncoder, 2)):
+        enc = cls(io.BytesIO(), da.CompressionOptions.default(), ctx)
+        ref = ob.Stream(ob.preset(ob.DEFAULT, wrapper))
+        if wrapper == 2:
+            ref.gzip_header(da.BLANK_GZIP_HEADER)
+        enc.write_all(data)
+        ref.write_all(data)
+        res1 = enc.reset(io.BytesIO()).getvalue()
+        assert res1 == ref.reset()
+        if wrapper == 2:
+            ref.gzip_header(da.BLANK_GZIP_HEADER)
+        enc.write_all(data)
+        ref.write_all(data)
+        res2 = enc.finish().getvalue()
+        assert res2 == ref.finish()
+        assert res1 == res2  # the reference's own assertion
+    enc = da.DeflateEncoder(io.BytesIO(), da.Compression.Default, ctx)
+    enc.write_all(data[:50000])
+    enc.flush()
+    a = enc.reset(io.BytesIO()).getvalue()
+    enc.write_all(data[50000:])
+    b = enc.finish().getvalue()
+    assert zlib.decompressobj(-15).decompress(a) == data[:50000]
+    assert b == ob.encode(data[50000:], level=ob.DEFAULT)
