@@ -308,15 +308,38 @@ struct ConstLimit {
 #define MI355_STAT(i, v)
 #define MI355_STAT_FLUSH(policy)
 #endif
+
+// A per-lane flag that lives across the iterations of match_walk_park.  On the GPU it is a lane mask
+// (one bit per lane, the same 64-bit value in every lane, i.e. a pair of scalar registers): the
+// state bookkeeping of the common step then runs on the scalar unit and the vector ALU, which bounds
+// k_match, only does the arithmetic.  (As plain bools the compiler keeps loop-carried flags as 0/1
+// in vector registers and spends three vector instructions per flag and step on them.)  On the
+// host it is 0 or 1.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint64_t lane_flag;
+__device__ __forceinline__ lane_flag lf_of(bool b) { return __ballot(b); }
+__device__ __forceinline__ bool lf_me(lane_flag f) { return __builtin_amdgcn_inverse_ballot_w64(f); }
+__device__ __forceinline__ bool lf_any(lane_flag f) { return f != 0; }
+__device__ __forceinline__ lane_flag lf_not(lane_flag f) { return ~f; }
+#else
+typedef uint32_t lane_flag;  // 0 or 1
+inline lane_flag lf_of(bool b) { return b ? 1u : 0u; }
+inline bool lf_me(lane_flag f) { return f != 0; }
+inline bool lf_any(lane_flag f) { return f != 0; }
+inline lane_flag lf_not(lane_flag f) { return f ^ 1u; }
+#endif
+
 template <int U, bool HAS_Q, class W, class Emit, class Next, class Policy, class Lim>
 MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t checks, uint32_t checks_q, Emit& emit,
                               const Policy& policy) {
-    // WALK: on a chain.  PARK: the current candidate passed the probe and waits for its compare.
-    // FIN: result ready (p == NO_POS: nothing to report), waits to report and to take a new position.
-    enum : uint32_t { IDLE = 0, WALK = 1, PARK = 2, FIN = 3 };
-    uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], st[U], dsave[U], len[U], mq[U];
+    // A slot is walking (on a chain), parked (the current candidate passed the probe and waits for its
+    // compare), finished (result ready -- p == NO_POS: nothing to report -- waits to report and to take
+    // a new position) or idle (none of the three).  All lanes of a wave stay in the loop until the
+    // whole wave is out of work (an idle slot does nothing but take part in the reads).
+    uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], dsave[U], len[U], mq[U];
     uint32_t rd[U], rv[U], ra[U], rb[U], ra2[U], rb2[U];
-    bool hq[U], ext[U];
+    lane_flag walk[U], park[U], fin[U], ext[U];
+    bool hq[U];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MI355_UNROLL _Pragma("unroll")
 #else
@@ -325,7 +348,9 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
     MI355_STAT_DECL
     MI355_UNROLL
     for (int s = 0; s < U; s++) {
-        st[s] = FIN;  // nothing to report yet: the first service hands out the first positions
+        walk[s] = lf_of(false);
+        park[s] = lf_of(false);
+        fin[s] = lf_of(true);  // nothing to report yet: the first service hands out the first positions
         p[s] = NO_POS;
         cand[s] = 0;  // (every slot takes part in the reads of the common step: keep them in range)
         best[s] = 1;
@@ -339,18 +364,18 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         hq[s] = true;
     }
     for (uint32_t iter = 0;; iter++) {
-        bool walking = false, pending = false;
+        lane_flag walking = lf_of(false), pending = lf_of(false);
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            walking = walking || st[s] == WALK;
-            pending = pending || st[s] >= PARK;
-            MI355_STAT(1, st[s] == WALK ? 1u : 0u)
-            MI355_STAT(4, st[s] == PARK ? 1u : 0u)
-            MI355_STAT(5, st[s] == FIN ? 1u : 0u)
-            MI355_STAT(6, st[s] == IDLE ? 1u : 0u)
+            walking = walking | walk[s];
+            pending = pending | park[s] | fin[s];
+            MI355_STAT(1, lf_me(walk[s]) ? 1u : 0u)
+            MI355_STAT(4, lf_me(park[s]) ? 1u : 0u)
+            MI355_STAT(5, lf_me(fin[s]) ? 1u : 0u)
+            MI355_STAT(6, (!lf_me(walk[s]) && !lf_me(park[s]) && !lf_me(fin[s])) ? 1u : 0u)
         }
         MI355_STAT(0, 1u)
-        if (!walking && !pending) break;
+        if (!lf_any(walking) && !lf_any(pending)) break;
         // The common step, branch free: link and probe of the current candidate are read together
         // (for a slot that is not walking the reads are harmless and their results unused), then
         // matching.rs:124-143 as selects.
@@ -361,30 +386,32 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         }
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            const bool walk = st[s] == WALK;
-            const bool hit = walk && (rv[s] & 0xffffu) == probe[s];   // :141-143, compare deferred
+            const lane_flag hit = walk[s] & lf_of((rv[s] & 0xffffu) == probe[s]);   // :141-143, compare deferred
+            const uint32_t c = cand[s] - rd[s];
+            // (c may wrap below the window start; p - c is then still the true distance, > 32768)
+            const lane_flag ok = lf_of(it[s] < checks) & lf_of(p[s] - c <= (uint32_t)WINDOW_SIZE);
+            const lane_flag miss = walk[s] & lf_not(hit);
+            const lane_flag adv = miss & ok;
             if (HAS_Q) {
-                const bool cap = walk && !hit && !hq[s] && it[s] == checks_q && it[s] < checks;
+                const bool cap = lf_me(miss) && !hq[s] && it[s] == checks_q && it[s] < checks;
                 mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
                 hq[s] = hq[s] || cap;
             }
-            const uint32_t c = cand[s] - rd[s];
-            // (c may wrap below the window start; p - c is then still the true distance, > 32768)
-            const bool ok = it[s] < checks && p[s] - c <= (uint32_t)WINDOW_SIZE;
-            const bool adv = walk && !hit && ok;
-            dsave[s] = hit ? rd[s] : dsave[s];
-            st[s] = walk ? (hit ? (uint32_t)PARK : (ok ? (uint32_t)WALK : (uint32_t)FIN)) : st[s];
-            cand[s] = adv ? c : cand[s];
-            it[s] += adv ? 1u : 0u;
+            dsave[s] = lf_me(hit) ? rd[s] : dsave[s];
+            park[s] = park[s] | hit;
+            fin[s] = fin[s] | (miss & lf_not(ok));
+            walk[s] = adv;
+            cand[s] = lf_me(adv) ? c : cand[s];
+            it[s] += lf_me(adv) ? 1u : 0u;
         }
-        walking = false;
-        pending = false;
+        walking = lf_of(false);
+        pending = lf_of(false);
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            walking = walking || st[s] == WALK;
-            pending = pending || st[s] >= PARK;
+            walking = walking | walk[s];
+            pending = pending | park[s] | fin[s];
         }
-        if (!policy(pending, walking, iter)) continue;
+        if (!policy(lf_me(pending), lf_me(walking), iter)) continue;
         MI355_STAT(2, 1u)
         // ---- service, written as selects as well: the few lanes that need a part of it are spread
         // over the wave, so every part runs for the whole wave anyway ----
@@ -392,12 +419,12 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         // matches on text end inside the first round); a slot whose compare the policy cuts short
         // stays parked and goes on next time
         MI355_UNROLL
-        for (int s = 0; s < U; s++) ext[s] = st[s] == PARK;
+        for (int s = 0; s < U; s++) ext[s] = park[s];
         for (uint32_t round = 0;; round++) {
-            bool any = false;
+            lane_flag any = lf_of(false);
             MI355_UNROLL
-            for (int s = 0; s < U; s++) any = any || ext[s];
-            if (!policy.keep_extending(any, round)) break;
+            for (int s = 0; s < U; s++) any = any | ext[s];
+            if (!policy.keep_extending(lf_me(any), round)) break;
             MI355_STAT(3, 1u)
             MI355_UNROLL
             for (int s = 0; s < U; s++) {
@@ -413,16 +440,16 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
                 const uint32_t n8 = z ? ((uint32_t)__builtin_ctzll(z) >> 3) : 8u;
                 uint32_t nl = len[s] + n8;
                 nl = nl < maxlen[s] ? nl : maxlen[s];
-                const bool stop = n8 < 8 || nl == maxlen[s];
-                len[s] = ext[s] ? nl : len[s];
-                ext[s] = ext[s] && !stop;
+                const lane_flag stop = lf_of(n8 < 8 || nl == maxlen[s]);
+                len[s] = lf_me(ext[s]) ? nl : len[s];
+                ext[s] = ext[s] & lf_not(stop);
             }
         }
         // (2) matching.rs:149-156 for the compares that are through, then :124-132 (loop header, link,
         // the two chain-end tests) for their slots
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            const bool done = st[s] == PARK && !ext[s];
+            const bool done = lf_me(park[s] & lf_not(ext[s]));
             const bool up = done && len[s] > best[s];
             best[s] = up ? len[s] : best[s];
             bestd[s] = up ? p[s] - cand[s] : bestd[s];
@@ -430,29 +457,32 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         }
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            const bool done = st[s] == PARK && !ext[s];
-            const bool full = done && best[s] == maxlen[s] && bestd[s] == p[s] - cand[s];  // this compare hit max_length
-            probe[s] = done ? (rv[s] & 0xffffu) : probe[s];
-            const bool more = done && !full && it[s] < checks;
+            const lane_flag done = park[s] & lf_not(ext[s]);
+            const bool dn = lf_me(done);
+            const bool full = dn && best[s] == maxlen[s] && bestd[s] == p[s] - cand[s];  // this compare hit max_length
+            probe[s] = dn ? (rv[s] & 0xffffu) : probe[s];
+            const bool more = dn && !full && it[s] < checks;
             if (HAS_Q) {
                 const bool cap = more && !hq[s] && it[s] == checks_q;
                 mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
                 hq[s] = hq[s] || cap;
             }
             const uint32_t c = cand[s] - dsave[s];
-            const bool go = more && p[s] - c <= (uint32_t)WINDOW_SIZE;  // dsave == 0xFFFF ("none") fails here
-            cand[s] = go ? c : cand[s];
-            it[s] += go ? 1u : 0u;
-            st[s] = done ? (go ? (uint32_t)WALK : (uint32_t)FIN) : st[s];
-            len[s] = done ? 0u : len[s];  // the next compare of this slot starts from byte 0 again
+            const lane_flag go = lf_of(more && p[s] - c <= (uint32_t)WINDOW_SIZE);  // dsave == 0xFFFF ("none") fails here
+            cand[s] = lf_me(go) ? c : cand[s];
+            it[s] += lf_me(go) ? 1u : 0u;
+            walk[s] = walk[s] | go;
+            fin[s] = fin[s] | (done & lf_not(go));
+            park[s] = park[s] & lf_not(done);
+            len[s] = dn ? 0u : len[s];  // the next compare of this slot starts from byte 0 again
         }
         // (3) finished slots report and take one new position each; a position without a candidate is
         // set up as finished (result 0) and reported at the next service
         MI355_UNROLL
         for (int s = 0; s < U; s++) {
-            const bool fin = st[s] == FIN;
+            const bool f = lf_me(fin[s]);
             uint32_t idx = NO_POS;
-            if (fin) {
+            if (f) {
                 if (p[s] != NO_POS) {
                     uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
                     emit(p[s], m, (HAS_Q && hq[s]) ? mq[s] : m);
@@ -469,21 +499,22 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             const bool ok = search && checks > 0 && d <= (uint32_t)WINDOW_SIZE;
             if (HAS_Q) {
                 const bool cap = ok && checks_q == 0;
-                mq[s] = fin ? 0u : mq[s];
-                hq[s] = fin ? (!HAS_Q || cap) : hq[s];
+                mq[s] = f ? 0u : mq[s];
+                hq[s] = f ? (!HAS_Q || cap) : hq[s];
             } else {
                 hq[s] = true;
             }
-            p[s] = fin ? (inr ? ix : (uint32_t)NO_POS) : p[s];
-            cand[s] = fin ? (ok ? ix - d : ix) : cand[s];
-            best[s] = fin ? 1u : best[s];
-            bestd[s] = fin ? 0u : bestd[s];
-            probe[s] = fin ? (p0 & 0xffffu) : probe[s];  // bytes 0,1 of P (matching.rs:110,141)
-            it[s] = fin ? (ok ? 1u : 0u) : it[s];
+            p[s] = f ? (inr ? ix : (uint32_t)NO_POS) : p[s];
+            cand[s] = f ? (ok ? ix - d : ix) : cand[s];
+            best[s] = f ? 1u : best[s];
+            bestd[s] = f ? 0u : bestd[s];
+            probe[s] = f ? (p0 & 0xffffu) : probe[s];  // bytes 0,1 of P (matching.rs:110,141)
+            it[s] = f ? (ok ? 1u : 0u) : it[s];
             const uint32_t left = nrel - ix;
-            maxlen[s] = fin ? (search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u) : maxlen[s];
-            len[s] = fin ? 0u : len[s];
-            st[s] = fin ? (ok ? (uint32_t)WALK : (have ? (uint32_t)FIN : (uint32_t)IDLE)) : st[s];
+            maxlen[s] = f ? (search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u) : maxlen[s];
+            len[s] = f ? 0u : len[s];
+            walk[s] = walk[s] | lf_of(f && ok);
+            fin[s] = lf_of(f && have && !ok);
         }
     }
     MI355_STAT_FLUSH(policy)
