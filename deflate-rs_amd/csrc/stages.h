@@ -338,6 +338,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
     // whole wave is out of work (an idle slot does nothing but take part in the reads).
     uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], dsave[U], len[U], mq[U];
     uint32_t rd[U], rv[U], ra[U], rb[U], ra2[U], rb2[U];
+    int32_t low[U];  // p - 32768: the lowest candidate in reach (matching.rs:102-106)
     lane_flag walk[U], park[U], fin[U], ext[U];
     bool hq[U];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -353,6 +354,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         fin[s] = lf_of(true);  // nothing to report yet: the first service hands out the first positions
         p[s] = NO_POS;
         cand[s] = 0;  // (every slot takes part in the reads of the common step: keep them in range)
+        low[s] = 0;
         best[s] = 1;
         bestd[s] = 0;
         probe[s] = 0;
@@ -388,8 +390,8 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         for (int s = 0; s < U; s++) {
             const lane_flag hit = walk[s] & lf_of((rv[s] & 0xffffu) == probe[s]);   // :141-143, compare deferred
             const uint32_t c = cand[s] - rd[s];
-            // (c may wrap below the window start; p - c is then still the true distance, > 32768)
-            const lane_flag ok = lf_of(it[s] < checks) & lf_of(p[s] - c <= (uint32_t)WINDOW_SIZE);
+            // (no link: rd = 0xFFFF and c falls below p - 65535 < low, as c <= cand <= p)
+            const lane_flag ok = lf_of(it[s] < checks) & lf_of((int32_t)c >= low[s]);
             const lane_flag miss = walk[s] & lf_not(hit);
             const lane_flag adv = miss & ok;
             if (HAS_Q) {
@@ -468,7 +470,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
                 hq[s] = hq[s] || cap;
             }
             const uint32_t c = cand[s] - dsave[s];
-            const lane_flag go = lf_of(more && p[s] - c <= (uint32_t)WINDOW_SIZE);  // dsave == 0xFFFF ("none") fails here
+            const lane_flag go = lf_of(more && (int32_t)c >= low[s]);  // dsave == 0xFFFF ("none") fails here
             cand[s] = lf_me(go) ? c : cand[s];
             it[s] += lf_me(go) ? 1u : 0u;
             walk[s] = walk[s] | go;
@@ -505,6 +507,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
                 hq[s] = true;
             }
             p[s] = f ? (inr ? ix : (uint32_t)NO_POS) : p[s];
+            low[s] = f ? (int32_t)ix - (int32_t)WINDOW_SIZE : low[s];
             cand[s] = f ? (ok ? ix - d : ix) : cand[s];
             best[s] = f ? 1u : best[s];
             bestd[s] = f ? 0u : bestd[s];
