@@ -301,12 +301,12 @@ struct WavePolicy {
 #endif
     __device__ bool operator()(bool pending, bool walking, uint32_t iter) const {
         if ((iter % MI355_MATCH_R) == MI355_MATCH_R - 1) return true;
-        return __ballot(walking) == 0;
+        return __builtin_amdgcn_ballot_w64(walking) == 0;
     }
     // the compare loop is worth its instructions while many lanes take part; a few long matches go
     // on at the next service instead of holding the whole wave
     __device__ bool keep_extending(bool any, uint32_t round) const {
-        uint32_t cnt = (uint32_t)__popcll(__ballot(any));
+        uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(any));
         return cnt >= MI355_EXT_DENSE || (round < MI355_EXT_ROUNDS && cnt > 0);
     }
 };

@@ -317,7 +317,7 @@ struct ConstLimit {
 // host it is 0 or 1.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef uint64_t lane_flag;
-__device__ __forceinline__ lane_flag lf_of(bool b) { return __ballot(b); }
+__device__ __forceinline__ lane_flag lf_of(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool lf_me(lane_flag f) { return __builtin_amdgcn_inverse_ballot_w64(f); }
 __device__ __forceinline__ bool lf_any(lane_flag f) { return f != 0; }
 __device__ __forceinline__ lane_flag lf_not(lane_flag f) { return ~f; }
