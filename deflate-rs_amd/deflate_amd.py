@@ -502,6 +502,32 @@ class Shard:
         self.nb = nb.value
         return [(c.dyn_bits, c.dyn_est, c.static_est, c.fixed_bits, c.in_bytes, c.q13) for c in costs[: nb.value]]
 
+    def blocks_raw(self, skip, d_tail_ptr, n_tail):
+        """-> (number of blocks, ctypes array of BlockCost): no per-block Python work (the distributed driver)"""
+        nb = C.c_uint64(0)
+        cap = 1 << 14
+        costs = (BlockCost * cap)()
+        rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, cap)
+        if rc != OK:
+            self.ctx._err(rc)
+        if nb.value > cap:
+            costs = (BlockCost * nb.value)()
+            rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, nb.value)
+            if rc != OK:
+                self.ctx._err(rc)
+        self.nb = nb.value
+        return nb.value, costs
+
+    def pack_raw(self, plans_arr, first, end_bit, d_out_ptr, out_cap):
+        """plans_arr: ctypes array of BlockInfo for the whole stream, `first` = index of this rank's first block"""
+        fb = C.c_uint64(0)
+        nbts = C.c_size_t(0)
+        ptr = C.cast(C.byref(plans_arr, first * C.sizeof(BlockInfo)), C.POINTER(BlockInfo))
+        rc = load().mi355_shard_pack(self._h, ptr, end_bit, C.c_void_p(d_out_ptr), out_cap, C.byref(fb), C.byref(nbts))
+        if rc != OK:
+            self.ctx._err(rc)
+        return fb.value, nbts.value
+
     def pack(self, plans, end_bit, d_out_ptr, out_cap):
         """plans: list of (btype, bfinal, bit_start) of this rank's blocks -> (first_byte, n_bytes)"""
         arr = (BlockInfo * max(1, len(plans)))()
@@ -524,6 +550,16 @@ class Shard:
             self.close()
         except Exception:
             pass
+
+
+def plan_blocks_raw(costs_arr, n, compat=0):
+    """plan_blocks over a ctypes array of BlockCost -> (ctypes array of BlockInfo, total_bits)"""
+    out = (BlockInfo * max(1, n))()
+    tot = C.c_uint64(0)
+    rc = load().mi355_plan_blocks(costs_arr, n, compat, out, C.byref(tot))
+    if rc != OK:
+        raise DeflateError(rc, "mi355_plan_blocks")
+    return out, tot.value
 
 
 def plan_blocks(costs, compat=0):

@@ -172,13 +172,27 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         dist.all_gather(allv, mine, group=group)
         return [t.tolist() for t in allv]
 
+    import os
+    import time
+    trace = os.environ.get("MI355_P1_TRACE") == "1"
+    marks = []
+
+    def mark(name):
+        if trace:
+            torch.cuda.synchronize(dev)
+            marks.append((name, time.perf_counter()))
+
+    mark("start")
     sh = da.Shard(ctx, d_ext.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total, options, compat,
                   torch.cuda.current_stream(dev).cuda_stream)
+    mark("links+match+exit tables")
     # exchange 1: exit tables -> entry positions
     tables = gather_ints(sh.exit_table())
     lays = [p1_layout(total, r, world) for r in range(world)]
     entries = p1_entries(lays, tables)
+    mark("x1 tables")
     n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
+    mark("emit")
     # exchange 2: token counts
     counts = [c[0] for c in gather_ints([n_tok])]
     skip, tail = p1_token_split(counts)
@@ -196,43 +210,65 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         tail_t = tail_c.to(dev)
     for q in reqs:
         q.wait()
-    costs = sh.blocks(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
-    # exchange 4: block costs (6 x int64 per block), padded to the largest rank
-    nbs = [c[0] for c in gather_ints([len(costs)])]
+    import ctypes
+    import numpy as np
+    mark("x2+x3 counts, straddling tokens")
+    nb, carr = sh.blocks_raw(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
+    # exchange 4: block costs (56 bytes per block) as raw bytes, padded to the largest rank; no per-block
+    # Python work anywhere on this path
+    mark("block costs")
+    csz = ctypes.sizeof(da.BlockCost)
+    nbs = [c[0] for c in gather_ints([nb])]
     mx = max(1, max(nbs))
-    flat = [0] * (mx * 6)
-    flat[: len(costs) * 6] = [int(v) for c in costs for v in c]
-    allf = gather_ints(flat)
-    allc = []
-    for r in range(world):
-        allc.extend(tuple(allf[r][i * 6:(i + 1) * 6]) for i in range(nbs[r]))
-    plans, total_bits = da.plan_blocks(allc, compat)
+    mine_c = torch.zeros(mx * csz, dtype=torch.uint8)
+    if nb:
+        mine_c[: nb * csz] = torch.from_numpy(np.frombuffer(carr, dtype=np.uint8, count=nb * csz).copy())
+    mine_c = mine_c.to(cdev)
+    allt = [torch.empty_like(mine_c) for _ in range(world)]
+    dist.all_gather(allt, mine_c, group=group)
+    flat = torch.cat([allt[r][: nbs[r] * csz] for r in range(world)]).cpu().numpy().tobytes()
+    ntot = sum(nbs)
+    allc = (da.BlockCost * max(1, ntot)).from_buffer_copy(flat.ljust(csz, b"\0"))
+    mark("x4 costs")
+    plans, total_bits = da.plan_blocks_raw(allc, ntot, compat)
+    mark("plan")
     b0 = sum(nbs[:rank])
-    mine_p = plans[b0:b0 + nbs[rank]]
-    end_bit = plans[b0 + nbs[rank]][2] if b0 + nbs[rank] < len(plans) else total_bits
+    end_bit = plans[b0 + nb].bit_start if b0 + nb < ntot else total_bits
     fb, nbytes = 0, 0
     dev_out = None
-    if mine_p:
-        cap = (end_bit - mine_p[0][2]) // 8 + 64
+    if nb:
+        cap = (end_bit - plans[b0].bit_start) // 8 + 64
         dev_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-        fb, nbytes = sh.pack(mine_p, end_bit, dev_out.data_ptr(), cap)
+        fb, nbytes = sh.pack_raw(plans, b0, end_bit, dev_out.data_ptr(), cap)
+    mark("pack")
     sh.close()
-    # exchange 5: byte ranges to rank 0, OR-ed (neighbours share the seam word)
+    # exchange 5: byte ranges to rank 0, all in flight at once (every peer has its own xGMI link to
+    # rank 0), then OR-ed in: neighbours share the seam byte
     meta = gather_ints([fb, nbytes])
     stream_len = (total_bits + 7) // 8
     if rank == 0:
         out = torch.zeros(stream_len + 16, dtype=torch.uint8, device=dev)
         if nbytes:
             out[fb:fb + nbytes] |= dev_out[:nbytes]
+        tmps, ops = {}, []
         for r in range(1, world):
             f, k = meta[r]
             if k:
-                tmp = torch.empty(k, dtype=torch.uint8, device=cdev)
-                dist.recv(tmp, src=r, group=group)
-                out[f:f + k] |= tmp.to(dev)
+                tmps[r] = torch.empty(k, dtype=torch.uint8, device=cdev)
+                ops.append(dist.P2POp(dist.irecv, tmps[r], r, group))
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            q.wait()
+        for r, t in tmps.items():
+            f, k = meta[r]
+            out[f:f + k] |= t.to(dev)
+        mark("x5 stitch")
+        if trace:
+            print("P1 rank 0 phases (ms): " + ", ".join("%s %.2f" % (marks[i][0], 1e3 * (marks[i][1] - marks[i - 1][1]))
+                                                      for i in range(1, len(marks))), flush=True)
         return out[:stream_len], stream_len
     if nbytes:
-        dist.send(dev_out[:nbytes].to(cdev).contiguous(), dst=0, group=group)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, dev_out[:nbytes].to(cdev).contiguous(), 0, group)]):
+            q.wait()
     return None, stream_len
 
 
