@@ -339,8 +339,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
     uint32_t p[U], cand[U], best[U], bestd[U], probe[U], it[U], maxlen[U], dsave[U], len[U], mq[U];
     uint32_t rd[U], rv[U], ra[U], rb[U], ra2[U], rb2[U];
     int32_t low[U];  // p - 32768: the lowest candidate in reach (matching.rs:102-106)
-    lane_flag walk[U], park[U], fin[U], ext[U];
-    bool hq[U];
+    lane_flag walk[U], park[U], fin[U], ext[U], hq[U];  // hq: the quarter-budget result is taken
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MI355_UNROLL _Pragma("unroll")
 #else
@@ -363,7 +362,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
         dsave[s] = 0;
         len[s] = 0;
         mq[s] = 0;
-        hq[s] = true;
+        hq[s] = lf_of(true);
     }
     for (uint32_t iter = 0;; iter++) {
         lane_flag walking = lf_of(false), pending = lf_of(false);
@@ -395,9 +394,9 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             const lane_flag miss = walk[s] & lf_not(hit);
             const lane_flag adv = miss & ok;
             if (HAS_Q) {
-                const bool cap = lf_me(miss) && !hq[s] && it[s] == checks_q && it[s] < checks;
-                mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
-                hq[s] = hq[s] || cap;
+                const lane_flag cap = miss & lf_not(hq[s]) & lf_of(it[s] == checks_q && it[s] < checks);
+                mq[s] = lf_me(cap) ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
+                hq[s] = hq[s] | cap;
             }
             dsave[s] = lf_me(hit) ? rd[s] : dsave[s];
             park[s] = park[s] | hit;
@@ -465,9 +464,9 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             probe[s] = dn ? (rv[s] & 0xffffu) : probe[s];
             const bool more = dn && !full && it[s] < checks;
             if (HAS_Q) {
-                const bool cap = more && !hq[s] && it[s] == checks_q;
-                mq[s] = cap ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
-                hq[s] = hq[s] || cap;
+                const lane_flag cap = lf_of(more && it[s] == checks_q) & lf_not(hq[s]);
+                mq[s] = lf_me(cap) ? m_pack(bestd[s] ? best[s] : 0, bestd[s]) : mq[s];
+                hq[s] = hq[s] | cap;
             }
             const uint32_t c = cand[s] - dsave[s];
             const lane_flag go = lf_of(more && (int32_t)c >= low[s]);  // dsave == 0xFFFF ("none") fails here
@@ -487,7 +486,7 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             if (f) {
                 if (p[s] != NO_POS) {
                     uint32_t m = m_pack(bestd[s] ? best[s] : 0, bestd[s]);
-                    emit(p[s], m, (HAS_Q && hq[s]) ? mq[s] : m);
+                    emit(p[s], m, (HAS_Q && lf_me(hq[s])) ? mq[s] : m);
                 }
                 idx = next();
             }
@@ -500,11 +499,8 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
             const uint32_t d = w.link_far(ix);
             const bool ok = search && checks > 0 && d <= (uint32_t)WINDOW_SIZE;
             if (HAS_Q) {
-                const bool cap = ok && checks_q == 0;
                 mq[s] = f ? 0u : mq[s];
-                hq[s] = f ? (!HAS_Q || cap) : hq[s];
-            } else {
-                hq[s] = true;
+                hq[s] = (hq[s] & lf_not(fin[s])) | lf_of(f && ok && checks_q == 0);
             }
             p[s] = f ? (inr ? ix : (uint32_t)NO_POS) : p[s];
             low[s] = f ? (int32_t)ix - (int32_t)WINDOW_SIZE : low[s];
