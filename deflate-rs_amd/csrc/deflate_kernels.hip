@@ -461,12 +461,33 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 // k_adv: lz77.rs:305-547 / rle.rs:23-71 seen from a restart position: how far does the parser
 // get before it is again in a state that depends on the position only.
 // ---------------------------------------------------------------------------------------------
+// M of a workgroup's 1024 positions plus a short halo, staged in LDS: the lazy step looks one entry
+// ahead per deferral (lz77.rs:351-355), a chain of dependent reads that is cheap from LDS
+constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 64;
+struct TileM {
+    const uint32_t* g;   // the table in global memory (beyond the halo)
+    const uint32_t* t;   // the staged tile
+    uint64_t j0;         // first position of the tile
+    __device__ uint32_t operator()(uint64_t i) const {
+        const uint64_t r = i - j0;
+        return r < ADV_TILE + ADV_HALO ? t[r] : g[i];
+    }
+};
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                              ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg) {
-    // four consecutive positions per lane: 16-byte loads of M, one 8-byte store of adv
-    uint64_t j0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    __shared__ uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
+    const uint64_t t0 = (uint64_t)blockIdx.x * ADV_TILE;
+    const bool useq = Mq != nullptr;
+    for (uint32_t i = threadIdx.x; i < ADV_TILE + ADV_HALO; i += 256) {  // (the tables are padded by 64 entries)
+        const uint64_t g = t0 + i;
+        sM[i] = g < (uint64_t)n + 64 ? M[g] : 0u;
+        if (useq) sQ[i] = g < (uint64_t)n + 64 ? Mq[g] : 0u;
+    }
+    __syncthreads();
+    // four consecutive positions per lane, one 8-byte store of adv
+    uint64_t j0 = t0 + (uint64_t)threadIdx.x * 4;
     if (j0 >= n) return;
-    GM m{M}, mq{Mq ? Mq : M};
+    TileM m{M, sM, t0}, mq{useq ? Mq : M, useq ? sQ : sM, t0};
     uint16_t a[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++)
