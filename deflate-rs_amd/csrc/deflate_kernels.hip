@@ -170,78 +170,77 @@ __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict
     // One wave, nothing else on its SIMD: every instruction counts.  Both arrays are padded by
     // LINKS_PAD entries, so the loads need no clamp, and they are addressed as base + 32-bit index.
     // hl/link of the groups one and two ahead are in flight while a group is worked on.
-    const uint16_t* hls = hl + start;
-    uint16_t* lks = link + start;
+    // Groups of LG batches run through four register stages: a group is worked on from its stage
+    // and the stage is then refilled with the group four ahead, so loaded values are touched only
+    // where they are used (no hand-over copies that would make the wave wait for loads it has just
+    // issued).  Running pointers with constant offsets: one 64-bit add per four groups.
+    constexpr int ST = 4;
+    constexpr uint32_t GP = 64 * LG;  // positions per group
+    const uint16_t* ph = hl + start + lane;
+    uint16_t* pl = link + start + lane;
     const uint32_t count = stop - start;
     const uint32_t own = c0 - start;  // the previous epoch comes first: it only warms the table
-    uint32_t chl[LG], nhl[LG], fhl[LG];
+    uint32_t H[ST][LG], K[ST][LG];
 #pragma unroll
-    for (int g = 0; g < LG; g++) {
-        const uint32_t i = 64 * g + lane;
-        chl[g] = hls[i];
-        nhl[g] = hls[i + 64 * LG];
-    }
-    for (uint32_t i0 = 0; i0 < own; i0 += 64 * LG) {  // (epochs are multiples of 64 * LG)
+    for (int r = 0; r < ST; r++)
 #pragma unroll
-        for (int g = 0; g < LG; g++) fhl[g] = hls[i0 + 64 * (2 * LG + g) + lane];
-        wave_lds_fence();
+        for (int g = 0; g < LG; g++) H[r][g] = ph[GP * r + 64 * g];
+    for (uint32_t i0 = 0; i0 < own; i0 += GP * ST) {  // (an epoch is 64 groups)
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            const uint32_t i = i0 + 64 * g + lane;
-            if (chl[g] >> 15) head[chl[g] & 0x7fff] = (uint16_t)(i + bias);  // (start + i + 2 < n holds before c0 <= n)
+        for (int r = 0; r < ST; r++) {
             wave_lds_fence();
-        }
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            chl[g] = nhl[g];
-            nhl[g] = fhl[g];
+            for (int g = 0; g < LG; g++) {
+                const uint32_t i = i0 + GP * r + 64 * g + lane;
+                const uint32_t v = H[r][g];
+                if (v >> 15) head[v & 0x7fff] = (uint16_t)(i + bias);  // (start + i + 2 < n holds before c0 <= n)
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int g = 0; g < LG; g++) H[r][g] = ph[GP * (ST + r) + 64 * g];
         }
+        ph += GP * ST;
     }
-    uint32_t clk[LG], nlk[LG], flk[LG];
+    pl += own;
 #pragma unroll
-    for (int g = 0; g < LG; g++) {
-        const uint32_t i = own + 64 * g + lane;
-        clk[g] = lks[i];
-        nlk[g] = lks[i + 64 * LG];
-    }
-    for (uint32_t i0 = own; i0 < count; i0 += 64 * LG) {
+    for (int r = 0; r < ST; r++)
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            const uint32_t i = i0 + 64 * (2 * LG + g) + lane;
-            fhl[g] = hls[i];
-            flk[g] = lks[i];
-        }
-        uint32_t stored[LG], rel[LG];
-        bool need[LG];
-        wave_lds_fence();
+        for (int g = 0; g < LG; g++) K[r][g] = pl[GP * r + 64 * g];
+    for (uint32_t i0 = own; i0 < count; i0 += GP * ST) {
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            const uint32_t i = i0 + 64 * g + lane;
-            const bool active = start + i + 2 < n && i < count;
-            const uint32_t h = chl[g] & 0x7fff;
-            rel[g] = i + bias;  // 0..65535
-            need[g] = active && clk[g] == 0;
-            const bool last = active && (chl[g] >> 15);
-            stored[g] = need[g] ? (uint32_t)head[h] : 0xFFFFu;
+        for (int r = 0; r < ST; r++) {
+            uint32_t stored[LG], rel[LG];
+            bool need[LG];
             wave_lds_fence();
-            if (last) head[h] = (uint16_t)rel[g];
-            wave_lds_fence();
-        }
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            const uint32_t i = i0 + 64 * g + lane;
-            if (need[g] && stored[g] < rel[g] && rel[g] - stored[g] <= WINDOW_SIZE) lks[i] = (uint16_t)(rel[g] - stored[g]);
-        }
+            for (int g = 0; g < LG; g++) {
+                const uint32_t i = i0 + GP * r + 64 * g + lane;
+                const bool active = start + i + 2 < n && i < count;
+                const uint32_t v = H[r][g];
+                const uint32_t h = v & 0x7fff;
+                rel[g] = i + bias;  // 0..65535
+                need[g] = active && K[r][g] == 0;
+                const bool last = active && (v >> 15);
+                stored[g] = need[g] ? (uint32_t)head[h] : 0xFFFFu;
+                wave_lds_fence();
+                if (last) head[h] = (uint16_t)rel[g];
+                wave_lds_fence();
+            }
 #pragma unroll
-        for (int g = 0; g < LG; g++) {
-            chl[g] = nhl[g];
-            clk[g] = nlk[g];
-            nhl[g] = fhl[g];
-            nlk[g] = flk[g];
+            for (int g = 0; g < LG; g++)
+                if (need[g] && stored[g] < rel[g] && rel[g] - stored[g] <= WINDOW_SIZE)
+                    pl[GP * r + 64 * g] = (uint16_t)(rel[g] - stored[g]);
+#pragma unroll
+            for (int g = 0; g < LG; g++) {
+                H[r][g] = ph[GP * (ST + r) + 64 * g];
+                K[r][g] = pl[GP * (ST + r) + 64 * g];
+            }
         }
+        ph += GP * ST;
+        pl += GP * ST;
     }
 }
-constexpr uint32_t LINKS_PAD = 64 * 3 * LG + 64;  // what k_links_b reads past the last position
+constexpr uint32_t LINKS_PAD = 64 * 8 * LG + 64;  // what k_links_b reads past the last position (stages ahead)
 
 // ---------------------------------------------------------------------------------------------
 // k_match: matching.rs:87-166 longest_match (prev_length = 0) for every position.  A workgroup
