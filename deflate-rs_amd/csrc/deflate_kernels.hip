@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in,
     bool active = p + 2 < n;
     uint32_t v = load_u32_clamped(in, p < n ? p : n - 1, n);
     uint32_t a = v & 0xff, b1 = (v >> 8) & 0xff, c = (v >> 16) & 0xff;
-    apply_rewarm(ov, p, a, b1);
-    uint32_t h = active ? hash3(a, b1, c) : 0;
+    const uint32_t ab = rewarm_ab(ov, p, a, b1);
+    uint32_t h = active ? hash3(ab & 0xff, ab >> 8, c) : 0;
     uint64_t peers = __ballot(active);
 #pragma unroll
     for (int b = 0; b < 15; b++) {

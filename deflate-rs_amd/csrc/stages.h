@@ -93,8 +93,9 @@ MI355_HD bool rewarm_listed(const HashOverride& ov, uint32_t p) {
     return false;
 }
 
-// replaces the first two bytes of position p's 3-byte hash input where a re-warm applies
-MI355_HD void apply_rewarm(const HashOverride& ov, uint64_t p, uint32_t& a, uint32_t& b) {
+// the first two bytes of position p's 3-byte hash input, replaced where a re-warm applies; returned
+// packed (a | b << 8) -- by value, so that nothing has to live in memory
+MI355_HD uint32_t rewarm_ab(const HashOverride& ov, uint64_t p, uint32_t a, uint32_t b) {
     if ((ov.on | ov.m) && p <= WINDOW_SIZE + 1) {
         bool first = (ov.on && p == ov.pos) || (ov.m && rewarm_listed(ov, (uint32_t)p));
         bool second = (ov.on && p == ov.pos + 1) || (ov.m && p > 0 && rewarm_listed(ov, (uint32_t)p - 1));
@@ -105,13 +106,13 @@ MI355_HD void apply_rewarm(const HashOverride& ov, uint64_t p, uint32_t& a, uint
             a = ov.b1;
         }
     }
+    return a | (b << 8);
 }
 
 template <class Bytes>
 MI355_HD uint32_t position_hash(const Bytes& by, uint64_t p, const HashOverride& ov) {
-    uint32_t a = by(p), b = by(p + 1), c = by(p + 2);
-    apply_rewarm(ov, p, a, b);
-    return hash3(a, b, c);
+    const uint32_t ab = rewarm_ab(ov, p, by(p), by(p + 1));
+    return hash3(ab & 0xff, ab >> 8, by(p + 2));
 }
 
 MI355_HD uint32_t ctz32(uint32_t x) {
