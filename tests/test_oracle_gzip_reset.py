@@ -73,3 +73,18 @@ def test_reset_gives_the_stream_of_a_fresh_encoder():
     b = s.finish()
     assert zlib.decompressobj(-15).decompress(a) == data[:50000]
     assert b == ob.encode(data[50000:], level=ob.DEFAULT)
+
+
+# the header builder of the Python mirror (no GPU needed): what Python's gzip reads back
+def test_gzip_header_builder_of_the_mirror():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deflate-rs_amd"))
+    import deflate_amd as da
+    assert da.gzip_header() == da.BLANK_GZIP_HEADER == BLANK
+    assert da.gzip_header(comment=b"Comment") == COMMENT
+    data = b"This is some test data" * 10
+    hdr = da.gzip_header(filename=b"name.txt", comment=b"a comment", extra=b"XY\x02\x00ab", mtime=1234567)
+    z = ob.encode_gzip(data, hdr, level=ob.DEFAULT)
+    f = gzip.GzipFile(fileobj=io.BytesIO(z))
+    assert f.read() == data
+    assert f.mtime == 1234567
