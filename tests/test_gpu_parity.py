@@ -555,3 +555,25 @@ def test_randomized_streams(da, ctx):
         assert not r.startswith("DIFF"), "seed %d: %s" % (seed, r)
         tally[r] = tally.get(r, 0) + 1
     assert tally.get("ok", 0) >= 140
+
+
+# the committed digests of the oracle's streams (tests/golden/oracle_digests.json): every reference fixture,
+# every level, raw / zlib / gzip
+def test_golden_digests(da, ctx):
+    import hashlib
+    import json
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import gen_digests
+    gold = json.load(open(os.path.join(HERE, "golden", "oracle_digests.json")))
+    seen = 0
+    for name, data in gen_digests.cases():
+        for lvl, (c, l, m) in gen_digests.LV.items():
+            for wname, w in (("raw", 0), ("zlib", 1), ("gzip", 2)):
+                key = "%s|%s|%s" % (name, lvl, wname)
+                if key not in gold["digests"]:
+                    continue
+                o = da.CompressionOptions(c, l, m)
+                z = ctx.encode_gzip(data, o, compat=1) if w == 2 else ctx.encode(data, o, wrapper=w, compat=1)
+                assert [len(z), hashlib.sha256(z).hexdigest()] == gold["digests"][key], key
+                seen += 1
+    assert seen == 390
