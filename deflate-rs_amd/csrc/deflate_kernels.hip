@@ -244,11 +244,14 @@ constexpr uint32_t LINKS_PAD = 64 * 8 * LG + 64;  // what k_links_b reads past t
 
 // ---------------------------------------------------------------------------------------------
 // k_match: matching.rs:87-166 longest_match (prev_length = 0) for every position.  A workgroup
-// stages the 32 KiB history + its 16 KiB tile + 258 lookahead bytes and the links of the same
-// range in LDS (144 KiB, one workgroup of 16 waves per CU); each lane owns 16 positions and keeps
-// four hash chains in flight (match_walk_multi).
+// stages the 32 KiB history + its 21 KiB tile + 258 lookahead bytes and the links of the same
+// range in LDS (159 of 160 KiB, one workgroup of 16 waves per CU); each lane keeps two hash chains
+// in flight and takes positions from a counter of the tile (match_walk_park in stages.h).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t MT = 16384;                               // positions per tile
+#ifndef MI355_MATCH_TILE
+#define MI355_MATCH_TILE 21504  // the largest multiple of 1024 whose window + links fit the 160 KiB of LDS
+#endif
+constexpr uint32_t MT = MI355_MATCH_TILE;                    // positions per tile (a multiple of 16)
 #ifndef MI355_MATCH_THREADS
 #define MI355_MATCH_THREADS 1024
 #endif
@@ -266,7 +269,7 @@ constexpr uint32_t MTHREADS = MI355_MATCH_THREADS;
 #define MI355_EXT_DENSE 1
 #endif
 constexpr uint32_t MCHAINS = MI355_MATCH_U;                  // chains in flight per lane
-constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // 49424, multiple of 16
+constexpr uint32_t MW_BYTES = WINDOW_SIZE + MT + 258 + 14;   // a multiple of 16
 constexpr uint32_t MW_LINKS = WINDOW_SIZE + MT;
 
 struct MatchEmit {
