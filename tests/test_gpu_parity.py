@@ -577,3 +577,56 @@ def test_golden_digests(da, ctx):
                 assert [len(z), hashlib.sha256(z).hexdigest()] == gold["digests"][key], key
                 seen += 1
     assert seen == 390
+
+
+# error behaviour of the C ABI (include/mi355_deflate.h): codes instead of panics, nothing written past a
+# buffer that is too small, handles that refuse use after finish
+def test_abi_error_paths(da, ctx):
+    import ctypes as C
+    L = da.load()
+    o = da.CompressionOptions.default().to_c(0, 0, 0)
+    data = datagen.text_like(50000, 3)
+    n = C.c_size_t(0)
+    # output buffer too small: the needed size comes back, the guard bytes stay untouched
+    small = (C.c_uint8 * 64)(*([0xAB] * 64))
+    rc = L.mi355_deflate_encode(ctx._h, data, len(data), C.byref(o), small, 16, C.byref(n))
+    assert rc == da.E_OUT_TOO_SMALL and n.value > 16
+    assert bytes(small[16:]) == b"\xAB" * 48
+    need = n.value
+    big = (C.c_uint8 * need)()
+    assert L.mi355_deflate_encode(ctx._h, data, len(data), C.byref(o), big, need, C.byref(n)) == da.OK
+    assert bytes(big[:n.value]) == ob.encode(data, level=ob.DEFAULT)
+    # bad arguments
+    assert L.mi355_deflate_encode(ctx._h, data, len(data), None, big, need, C.byref(n)) == da.E_ARG
+    assert L.mi355_deflate_encode(ctx._h, None, 5, C.byref(o), big, need, C.byref(n)) == da.E_ARG
+    bad = da.CompressionOptions.default().to_c(3, 0, 0)  # wrapper 3 does not exist
+    assert L.mi355_deflate_encode(ctx._h, data, len(data), C.byref(bad), big, need, C.byref(n)) == da.E_ARG
+    bad = da.CompressionOptions.default().to_c(0, 0, 2)  # flush mode 2 does not exist
+    assert L.mi355_deflate_encode(ctx._h, data, len(data), C.byref(bad), big, need, C.byref(n)) == da.E_ARG
+    assert L.mi355_deflate_encode_gzip(ctx._h, data, len(data), C.byref(o), None, 0, big, need, C.byref(n)) == da.E_ARG
+    # a device output pointer must be 4-byte aligned
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    out = torch.empty(da.bound(len(data)) + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.mi355_deflate_encode_device(ctx._h, C.c_void_p(t.data_ptr()), len(data), C.byref(o),
+                                       C.c_void_p(out.data_ptr() + 1), out.numel() - 1, C.byref(n), None)
+    assert rc == da.E_ARG
+    # streams: use after finish, gzip header on a non-gzip stream or after data
+    h = C.c_void_p()
+    assert L.mi355_deflate_stream_new(ctx._h, C.byref(o), C.byref(h)) == da.OK
+    assert L.mi355_deflate_stream_gzip_header(h, b"\x1f\x8b", 2) == da.E_STATE
+    assert L.mi355_deflate_stream_write(h, data, 100) == da.OK
+    assert L.mi355_deflate_stream_finish(h) == da.OK
+    assert L.mi355_deflate_stream_write(h, data, 100) == da.E_STATE
+    assert L.mi355_deflate_stream_flush(h) == da.E_STATE
+    assert L.mi355_deflate_stream_finish(h) == da.E_STATE
+    assert L.mi355_deflate_stream_reset(h, None, None) == da.E_STATE
+    L.mi355_deflate_stream_free(h)
+    g = da.CompressionOptions.default().to_c(2, 0, 0)
+    assert L.mi355_deflate_stream_new(ctx._h, C.byref(g), C.byref(h)) == da.OK
+    assert L.mi355_deflate_stream_write(h, data, 100) == da.OK
+    assert L.mi355_deflate_stream_gzip_header(h, b"\x1f\x8b", 2) == da.E_STATE  # the header goes out with the first write
+    L.mi355_deflate_stream_free(h)
+    # the context still works after all of that
+    assert ctx.encode(data) == ob.encode(data, level=ob.DEFAULT)
