@@ -630,3 +630,28 @@ def test_abi_error_paths(da, ctx):
     L.mi355_deflate_stream_free(h)
     # the context still works after all of that
     assert ctx.encode(data) == ob.encode(data, level=ob.DEFAULT)
+
+
+# two contexts used from two threads at once (the reference's encoders are independent objects; here one
+# context = one HIP stream + workspace, no shared mutable state between contexts)
+def test_two_contexts_two_threads(da):
+    import threading
+    datas = [datagen.text_like(700000, 21), datagen.mixed(900000, 22)]
+    refs = [ob.encode(d, level=ob.DEFAULT) for d in datas]
+    errs = []
+
+    def work(i):
+        c = da.Context(0)
+        try:
+            for _ in range(15):
+                if c.encode(datas[i]) != refs[i]:
+                    errs.append(i)
+        finally:
+            c.close()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
