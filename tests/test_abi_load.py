@@ -58,3 +58,16 @@ def test_product_never_references_the_oracle():
                 src = open(os.path.join(base, f), errors="ignore").read()
                 assert "deflref" not in src and "oracle_binding" not in src and "hostsim" not in src.replace(
                     "tests/hostsim", ""), f
+
+
+# the header is plain C: a C program over it (examples/mi355_deflate_cli.c) compiles with gcc and links
+# against the library -- no C++ and no torch types anywhere on the boundary
+def test_header_is_plain_c_and_the_example_links(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cli")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "examples", "mi355_deflate_cli.c"), "-L", os.path.join(root, "deflate-rs_amd"),
+           "-lmi355deflate", "-Wl,-rpath," + os.path.join(root, "deflate-rs_amd"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

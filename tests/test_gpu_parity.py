@@ -655,3 +655,26 @@ def test_two_contexts_two_threads(da):
     for t in ts:
         t.join()
     assert not errs
+
+
+# the plain-C example over the ABI (examples/mi355_deflate_cli.c), built with gcc and run as a process
+def test_c_example_program(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "cli")
+    subprocess.run(["gcc", "-O2", "-std=c99", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "mi355_deflate_cli.c"), "-L", os.path.join(ROOT, "deflate-rs_amd"),
+                    "-lmi355deflate", "-Wl,-rpath," + os.path.join(ROOT, "deflate-rs_amd"), "-o", exe], check=True)
+    src = os.path.join(FIX, "pg11.txt")
+    data = open(src, "rb").read()
+    blank = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff])
+    for flag, lvl, expect in (("-raw", ("-default", ob.DEFAULT), None), ("-zlib", ("-best", ob.BEST), None),
+                              ("-gzip", ("-fast", ob.FAST), None)):
+        for extra in ([], ["-chunk", "5000"]):
+            out = str(tmp_path / "out.bin")
+            subprocess.run([exe, flag, lvl[0]] + extra + [src, out], check=True, capture_output=True)
+            got = open(out, "rb").read()
+            if flag == "-gzip":
+                want = ob.encode_gzip(data, blank, level=lvl[1])
+            else:
+                want = ob.encode(data, level=lvl[1], wrapper=1 if flag == "-zlib" else 0)
+            assert got == want, (flag, lvl[0], extra)
