@@ -660,41 +660,67 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (lane == 0) cnt[k] = running;
 }
 
-// k_scan: exclusive scan of the per-segment token counts (single workgroup).  Each wave owns a
-// contiguous sixteenth and walks it 64 counts at a time (coalesced), scanning in registers; the
-// sixteen totals are scanned through LDS and added in a second walk.
-__global__ __launch_bounds__(1024) void k_scan(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base,
-                                               DevScalars* sc) {
+// k_scan_a / k_scan_b: exclusive scan of the per-segment token counts.  A workgroup takes 1024
+// counts: (a) its sum; (b) the sums of the workgroups before it, added to a scan of its own counts
+// (wave scans in registers, the sixteen wave totals through LDS).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(v, off, 64);
+        if (lane >= (uint32_t)off) v += y;
+    }
+    return v;
+}
+__global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ part) {
     __shared__ uint32_t wtot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t per = ((K + 15) / 16 + 63) / 64 * 64;  // per wave, a multiple of 64
-    const uint32_t lo = wv * per < K ? wv * per : K;
-    const uint32_t hi = lo + per < K ? lo + per : K;
-    uint32_t run = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const uint32_t v = i < hi ? cnt[i] : 0;
-        uint32_t x = v;
+    const uint32_t i = blockIdx.x * 1024 + tid;
+    uint32_t v = i < K ? cnt[i] : 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t y = __shfl_up(x, off, 64);
-            if (lane >= (uint32_t)off) x += y;
-        }
-        if (i < hi) base[i] = run + x - v;
-        run += __shfl(x, 63, 64);
-    }
-    if (lane == 0) wtot[wv] = run;
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) wtot[wv] = v;
     __syncthreads();
-    uint32_t add = 0, T = 0;
-    for (uint32_t k = 0; k < 16; k++) {
-        add += k < wv ? wtot[k] : 0;
-        T += wtot[k];
-    }
-    for (uint32_t i = lo + lane; i < hi; i += 64) base[i] += add;
     if (tid == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += wtot[k];
+        part[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ part,
+                                                 uint32_t* __restrict__ base, DevScalars* sc) {
+    __shared__ uint32_t wtot[16], red[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // sum of the workgroups before this one
+    uint32_t pre = 0;
+    for (uint32_t j = tid; j < blockIdx.x; j += 1024) pre += part[j];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 0) red[wv] = pre;
+    const uint32_t i = blockIdx.x * 1024 + tid;
+    const uint32_t v = i < K ? cnt[i] : 0;
+    const uint32_t x = wave_incl_scan(v, lane);
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    uint32_t add = 0, all = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        add += red[k];
+        add += k < wv ? wtot[k] : 0;
+        all += wtot[k];
+    }
+    if (i < K) base[i] = add + x - v;
+    if (tid == 0 && blockIdx.x == gridDim.x - 1) {
+        uint32_t T = 0;
+        for (uint32_t k = 0; k < 16; k++) T += red[k];
+        T += all;
         sc->T = T;
         sc->nb = T / MAX_BUFFER_LENGTH + 1;
     }
+}
+// K == 0: no tokens
+__global__ void k_scan_zero(DevScalars* sc) {
+    if (threadIdx.x || blockIdx.x) return;
+    sc->T = 0;
+    sc->nb = 1;
 }
 
 // k_compact: tokens of all segments into one dense stream.
