@@ -1014,12 +1014,15 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         uint32_t b = b0 + lane;
         bool have = b < nb;
         uint64_t dyn_bits = 0, dyn_est = 0, static_est = 0, fixed_bits = 0, in_bytes = 0;
+        uint32_t my_sync = 0, my_q13 = 0;  // everything the serial walk needs is loaded here, 64 blocks at a time
         if (have) {
             dyn_bits = hdr[b].dyn_bits;
             dyn_est = hdr[b].dyn_est;
             static_est = hdr[b].static_est;
             fixed_bits = hdr[b].fixed_bits;
             in_bytes = (uint64_t)bstart[b + 1] - bstart[b];
+            my_sync = blk_sync[b];
+            my_q13 = q13[b];
         }
         // f(phase) for the 8 possible phases is tiny, but a plain in-order walk is enough here
         uint32_t cnt = nb - b0 < 64 ? nb - b0 : 64;
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             uint64_t len = 0;
             if (lane == sidx) {
                 BlockPlan p;
-                const bool sync = blk_sync[b] != 0;
+                const bool sync = my_sync != 0;
                 plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == nb) && !sync, bitpos, &p);
                 plan[b] = p;
                 len = p.bit_len;
@@ -1039,9 +1042,9 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
                 }
                 if (p.btype == BT_STORED) {
                     n_st++;
-                    if (q13[b]) {
+                    if (my_q13) {
                         hits++;
-                        if (q13[b] == 2 && (compat & 1)) panic = 1;
+                        if (my_q13 == 2 && (compat & 1)) panic = 1;
                     }
                 } else if (p.btype == BT_FIXED) {
                     n_fx++;
