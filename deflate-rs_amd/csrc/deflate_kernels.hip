@@ -1127,11 +1127,32 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
                 put_bits(out32, hb, (piece & 0xffff) | (((~piece) & 0xffff) << 16), 32);
             }
             uint64_t ob = (hb >> 3) + 4;  // first payload byte
-            // whole output words in the middle are plain stores; ragged ends go byte-wise via OR
-            for (uint64_t i = tid; i < piece; i += 256) {
-                uint64_t o = ob + i;
-                uint32_t v = (src + i < n) ? in[src + i] : 0u;
-                if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
+            // The output words that lie wholly inside the payload belong to this piece alone: plain
+            // 4-byte stores (the source is read byte-wise, it has no alignment to speak of).  The up
+            // to three bytes before the first and after the last whole word share their words with
+            // the header or with the next block: OR.
+            const uint64_t w0 = (ob + 3) >> 2, w1 = (ob + piece) >> 2;  // whole words [w0, w1)
+            if (w1 > w0) {
+                for (uint64_t w = w0 + tid; w < w1; w += 256) {
+                    const uint64_t i = (w << 2) - ob;  // payload offset of the word's first byte
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v |= ((src + i + k < n) ? (uint32_t)in[src + i + k] : 0u) << (8 * k);
+                    out32[w] = v;
+                }
+                const uint64_t headn = (w0 << 2) - ob, tail0 = (w1 << 2) - ob;
+                for (uint64_t i = tid; i < headn + (piece - tail0); i += 256) {
+                    const uint64_t j = i < headn ? i : tail0 + (i - headn);
+                    const uint64_t o = ob + j;
+                    uint32_t v = (src + j < n) ? in[src + j] : 0u;
+                    if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
+                }
+            } else {
+                for (uint64_t i = tid; i < piece; i += 256) {
+                    uint64_t o = ob + i;
+                    uint32_t v = (src + i < n) ? in[src + i] : 0u;
+                    if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
+                }
             }
             bp = (ob + piece) * 8;
             src += piece;

@@ -99,3 +99,51 @@ def mixed(n, seed):
                 s = len(out) - d
                 out += out[s:s + min(ln, d)]
     return bytes(out[:n])
+
+
+def silesia_like(seed=0x53494C45, scale=1.0):
+    """about 211.9 MB in twelve pieces by entropy class, with the sizes of
+    the Silesia corpus files: text (10.2, 6.6, 41.5 MB), structured binary records (51.2, 6.2, 21.6 MB),
+    repetitive database rows (33.6, 10.1 MB), smooth 16-bit samples (10.0, 8.5 MB), near-incompressible
+    (7.3 MB), markup-heavy text (5.3 MB).  `scale` shrinks every piece (tests)."""
+    rng = np.random.default_rng(seed)
+    mb = lambda x: max(1000, int(x * 1e6 * scale))
+
+    def records(n, width, seed2):
+        r = np.random.default_rng(seed2)
+        rows = n // width + 1
+        tpl = r.integers(0, 256, size=width, dtype=np.uint8)
+        a = np.tile(tpl, (rows, 1))
+        cnt = np.arange(rows, dtype=np.uint32)
+        a[:, 4:8] = cnt.view(np.uint8).reshape(rows, 4)                      # a running counter
+        k = max(1, width // 8)
+        cols = r.choice(np.arange(8, width), size=k, replace=False)
+        a[:, cols] = r.integers(0, 16, size=(rows, k), dtype=np.uint8)        # a few low-entropy fields
+        hot = r.random(rows) < 0.02
+        a[hot, 8:] = r.integers(0, 256, size=(int(hot.sum()), width - 8), dtype=np.uint8)  # the odd noisy record
+        return a.reshape(-1)[:n].tobytes()
+
+    def rows_db(n, seed2):
+        r = np.random.default_rng(seed2)
+        pool = text_like(400 * 160, int(r.integers(1 << 30)))
+        lens = r.integers(60, 160, size=400)
+        base = [pool[i * 160:i * 160 + int(lens[i])] for i in range(400)]
+        idx = r.integers(0, len(base), size=n // 100 + 1)
+        rows = [base[j] + (b"|%08d\n" % (i * 7)) for i, j in enumerate(idx.tolist())]
+        return b"".join(rows)[:n].ljust(n, b"\n")
+
+    def samples16(n, seed2):
+        r = np.random.default_rng(seed2)
+        d = r.integers(-24, 25, size=n // 2 + 1, dtype=np.int32)
+        v = (np.cumsum(d) + 30000).astype(np.uint16)
+        return v.view(np.uint8)[:n].tobytes()
+
+    parts = [text_like(mb(10.2), int(rng.integers(1 << 30))), text_like(mb(6.6), int(rng.integers(1 << 30))),
+             text_like(mb(41.5), int(rng.integers(1 << 30))),
+             records(mb(51.2), 96, int(rng.integers(1 << 30))), records(mb(6.2), 40, int(rng.integers(1 << 30))),
+             records(mb(21.6), 256, int(rng.integers(1 << 30))),
+             rows_db(mb(33.6), int(rng.integers(1 << 30))), rows_db(mb(10.1), int(rng.integers(1 << 30))),
+             samples16(mb(10.0), int(rng.integers(1 << 30))), samples16(mb(8.5), int(rng.integers(1 << 30))),
+             rng_bytes(mb(7.3), int(rng.integers(1 << 30))),
+             text_like(mb(5.3), int(rng.integers(1 << 30)))]
+    return b"".join(parts)
