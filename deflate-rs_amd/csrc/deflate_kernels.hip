@@ -251,7 +251,10 @@ constexpr uint32_t LINKS_PAD = 64 * 8 * LG + 64;  // what k_links_b reads past t
 #ifndef MI355_MATCH_TILE
 #define MI355_MATCH_TILE 21504  // the largest multiple of 1024 whose window + links fit the 160 KiB of LDS
 #endif
-constexpr uint32_t MT = MI355_MATCH_TILE;                    // positions per tile (a multiple of 16)
+constexpr uint32_t MT = MI355_MATCH_TILE;                    // most positions per tile (a multiple of 64)
+// The tile size of a launch is chosen on the host (match_tile): the largest that fits, shrunk so that
+// the tiles come in whole rounds over the CUs, and smaller still for inputs that would not give
+// every CU a tile.
 #ifndef MI355_MATCH_THREADS
 #define MI355_MATCH_THREADS 1024
 #endif
@@ -330,7 +333,7 @@ template <bool HAS_Q>
 __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ in, uint32_t n,
                                                     const uint16_t* __restrict__ link, uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
-                                                    int in_aligned4, SegEnds sg) {
+                                                    int in_aligned4, SegEnds sg, uint32_t mt) {
     // one block, bytes first: both arrays then start below 64 KiB and their base folds into the
     // 16-bit offset field of the ds_read instructions
     __shared__ __attribute__((aligned(16))) uint8_t s_win[MW_BYTES + 2 * MW_LINKS];
@@ -338,11 +341,12 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
     uint16_t* const s_link = reinterpret_cast<uint16_t*>(s_win + MW_BYTES);
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x;
-    const uint64_t E = (uint64_t)blockIdx.x * MT;
+    const uint64_t E = (uint64_t)blockIdx.x * mt;
+    const uint32_t wbytes = WINDOW_SIZE + mt + 258 + 14, wlinks = WINDOW_SIZE + mt;  // multiples of 16 / 8
     const uint64_t wstart = E >= WINDOW_SIZE ? E - WINDOW_SIZE : 0;
     uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_bytes);
     if (in_aligned4) {
-        for (uint32_t w = tid; w < MW_BYTES / 16; w += MTHREADS) {
+        for (uint32_t w = tid; w < wbytes / 16; w += MTHREADS) {
             uint64_t g = wstart + 16ull * w;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (g + 16 <= n) {
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
             reinterpret_cast<uint4*>(s_bytes)[w] = v;
         }
     } else {
-        for (uint32_t w = tid; w < MW_BYTES / 4; w += MTHREADS) {
+        for (uint32_t w = tid; w < wbytes / 4; w += MTHREADS) {
             uint64_t g = wstart + 4ull * w;
             uint32_t v = 0;
             for (int b = 0; b < 4; b++)
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
             sb32[w] = v;
         }
     }
-    for (uint32_t w = tid; w < MW_LINKS / 8; w += MTHREADS) {
+    for (uint32_t w = tid; w < wlinks / 8; w += MTHREADS) {
         uint64_t g = wstart + 8ull * w;  // link is 256-byte aligned and wstart a multiple of 8
         uint4 v = make_uint4(0, 0, 0, 0);
         if (g + 8 <= n) {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
     __syncthreads();
     LdsWin win{s_bytes, s_link};
     MatchEmit emit{M, HAS_Q ? Mq : nullptr, wstart};
-    TileNext next{&s_next, (uint32_t)(E - wstart), MT};
+    TileNext next{&s_next, (uint32_t)(E - wstart), mt};
 #ifdef MI355_MATCH_STATS
     const unsigned long long t_start = wall_clock64();
     WavePolicy pol{&s_wgmax, &s_wgend, &s_wgsum, t_start};
