@@ -105,20 +105,22 @@ def main():
             prev = torch.empty(shard.HISTORY, dtype=torch.uint8, device=cdev)
         if rank < world - 1:
             nxt = torch.empty(shard.LOOKAHEAD, dtype=torch.uint8, device=cdev)
-        reqs = []
+        # all four transfers of a rank in one group: posted one by one, the sends of neighbouring ranks
+        # would wait for each other's receives
+        ops = []
         if rank < world - 1:
-            reqs.append(dist.isend(d_in[size - shard.HISTORY:].to(cdev).contiguous(), dst=rank + 1))
+            ops.append(dist.P2POp(dist.isend, d_in[size - shard.HISTORY:].to(cdev).contiguous(), rank + 1))
+            ops.append(dist.P2POp(dist.irecv, nxt, rank + 1))
         if rank > 0:
-            reqs.append(dist.isend(d_in[: shard.LOOKAHEAD].to(cdev).contiguous(), dst=rank - 1))
+            ops.append(dist.P2POp(dist.isend, d_in[: shard.LOOKAHEAD].to(cdev).contiguous(), rank - 1))
+            ops.append(dist.P2POp(dist.irecv, prev, rank - 1))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
         if rank > 0:
-            dist.recv(prev, src=rank - 1)
             parts.append(prev.cuda())
         parts.append(d_in)
         if rank < world - 1:
-            dist.recv(nxt, src=rank + 1)
             parts.append(nxt.cuda())
-        for q in reqs:
-            q.wait()
         parts.append(torch.zeros(64, dtype=torch.uint8, device="cuda"))
         d_ext = torch.cat(parts)
         assert d_ext.numel() - 64 == layout["g_hi"] - layout["g_lo"]

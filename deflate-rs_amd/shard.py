@@ -197,19 +197,18 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     counts = [c[0] for c in gather_ints([n_tok])]
     skip, tail = p1_token_split(counts)
     # exchange 3: the head tokens of rank r+1 complete the last block of rank r
-    reqs = []
+    ops = []  # (one group per rank: a send posted before the matching receive of the neighbour must not block it)
     if rank > 0 and skip[rank]:
         head = torch.empty(skip[rank], dtype=torch.int32, device=dev)
         ctypes_copy_d2d(head.data_ptr(), tok_ptr, skip[rank] * 4)
-        head_c = head.to(cdev)
-        reqs.append(dist.isend(head_c, dst=rank - 1, group=group))
-    tail_t = None
+        ops.append(dist.P2POp(dist.isend, head.to(cdev), rank - 1, group))
+    tail_c = None
     if tail[rank]:
         tail_c = torch.empty(tail[rank], dtype=torch.int32, device=cdev)
-        dist.recv(tail_c, src=rank + 1, group=group)
-        tail_t = tail_c.to(dev)
-    for q in reqs:
+        ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1, group))
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
         q.wait()
+    tail_t = tail_c.to(dev) if tail_c is not None else None
     import ctypes
     import numpy as np
     mark("x2+x3 counts, straddling tokens")
