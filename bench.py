@@ -91,6 +91,7 @@ def main():
     cap = da.bound(size) + 8
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     ctx = da.Context(dev_index)
+    ctx.reserve(size + (shard.HISTORY + shard.LOOKAHEAD if world > 1 else 0))  # set-up, like the context itself
     stream = torch.cuda.current_stream().cuda_stream
     flush = shard.flush_mode_for(rank, world)
     total = world * size
@@ -121,6 +122,18 @@ def main():
         parts.append(d_in)
         if rank < world - 1:
             parts.append(nxt.cuda())
+        # open the other connections the timed steps use (every rank -> rank 0 for the stitch, all-gather), so
+        # that the lazy set-up of RCCL's channels is not timed even with --warmup 0
+        one = torch.zeros(1, dtype=torch.uint8, device=cdev)
+        if rank == 0:
+            tmp = [torch.zeros(1, dtype=torch.uint8, device=cdev) for _ in range(world - 1)]
+            ops = [dist.P2POp(dist.irecv, tmp[r - 1], r) for r in range(1, world)]
+        else:
+            ops = [dist.P2POp(dist.isend, one, 0)]
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+        dist.all_gather([torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)],
+                        torch.zeros(1, dtype=torch.int64, device=cdev))
         parts.append(torch.zeros(64, dtype=torch.uint8, device="cuda"))
         d_ext = torch.cat(parts)
         assert d_ext.numel() - 64 == layout["g_hi"] - layout["g_lo"]

@@ -145,6 +145,7 @@ def load():
     L.mi355_shard_end.argtypes = [C.c_void_p]
     L.mi355_shard_end.restype = None
     L.mi355_adler32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
+    L.mi355_deflate_ctx_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.mi355_crc32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p]
     L.mi355_deflate_encode_gzip.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t,
                                             u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -172,7 +173,8 @@ EXPORTED = [
     "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_flush",
     "mi355_deflate_stream_finish",
     "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
-    "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset", "mi355_deflate_encode_gzip",
+    "mi355_deflate_ctx_reserve", "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset",
+    "mi355_deflate_encode_gzip",
     "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
     "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end",
@@ -205,6 +207,12 @@ class Context:
 
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
+
+    def reserve(self, in_len, host_api=False):
+        """mi355_deflate_ctx_reserve: allocate for inputs of up to in_len bytes now"""
+        rc = load().mi355_deflate_ctx_reserve(self._h, in_len, 1 if host_api else 0)
+        if rc != OK:
+            self._err(rc)
 
     def encode(self, data, options=Compression.Default, wrapper=0, compat=0, flush=0):
         """Host bytes in, host bytes out (mi355_deflate_encode)."""

@@ -97,6 +97,12 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 int mi355_deflate_encode(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
                          uint8_t* out, size_t out_cap, size_t* out_len);
 
+/* Allocate now what encodes of up to in_len bytes need (the workspace is about 20 bytes per input byte
+ * and only ever grows; with host_api != 0 also the device staging buffers of mi355_deflate_encode), so
+ * that the first call does not pay for it.  No reference item: the reference's encoders allocate their
+ * 330 KiB in ::new (src/deflate_state.rs:82-119). */
+int mi355_deflate_ctx_reserve(mi355_deflate_ctx* ctx, size_t in_len, int host_api);
+
 /* Same computation with input and output resident in device memory (no PCIe in the path):
  * compress_data_dynamic + compress_until_done(.., Flush::Finish) (src/lib.rs:110-122,
  * src/writer.rs:15-58) over d_in[0..in_len).  d_out needs mi355_deflate_bound(in_len) bytes
