@@ -1096,6 +1096,21 @@ __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint6
     if (hi) atomicOr(out32 + w + 2, hi);
 }
 
+// A wave's 256 tokens of a round take at most 256 * 48 bits: they are OR-ed together in LDS and go out as
+// whole words with plain stores; only the first and the last word of the wave's bit range, which it
+// shares with its neighbours, are OR-ed into the output.
+constexpr uint32_t PACK_WORDS = 256 * 48 / 32 + 4;
+__device__ __forceinline__ void put_bits_lds(uint32_t* buf, uint32_t bitpos, uint64_t bits, uint32_t nbits) {
+    if (nbits == 0) return;
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t lo = bits << sh;
+    const uint32_t hi = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+    const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+    if (w0) atomicOr(buf + w, w0);
+    if (w1) atomicOr(buf + w + 1, w1);
+    if (hi) atomicOr(buf + w + 2, hi);
+}
+
 struct PackLds {
     uint16_t llc[288];
     uint16_t dc[32];
@@ -1104,6 +1119,7 @@ struct PackLds {
     uint8_t dl[32];
     uint32_t scan[256];
     uint32_t carry;
+    uint32_t wbuf[4][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
 };
 
 __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, uint32_t n,
@@ -1175,6 +1191,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
     for (uint32_t i = tid; i < 288; i += 256) s.llc[i] = 0;
     if (tid < 32) s.dc[tid] = 0;
     if (tid < 20) s.clc[tid] = 0;
+    for (uint32_t i = tid; i < 4 * PACK_WORDS; i += 256) (&s.wbuf[0][0])[i] = 0;
     __syncthreads();
     if (tid == 0) canonical_codes(s.lll, 288, s.llc);  // huffman_table.rs:253-278
     if (tid == 64) canonical_codes(s.dl, 32, s.dc);
@@ -1254,12 +1271,27 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
             if (k < wv) wbase += v;
             total += v;
         }
-        uint64_t pos = bp + wbase + (incl - mine);
+        const uint64_t wstart = bp + wbase;              // first bit of this wave's tokens
+        const uint32_t wlen = s.scan[wv];                 // and how many bits they take
+        const uint64_t word0 = wstart >> 5;
+        const uint32_t nwords = wlen ? (uint32_t)(((wstart + wlen + 31) >> 5) - word0) : 0u;
+        uint32_t rel = (uint32_t)(wstart & 31) + (incl - mine);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            put_bits(out32, pos, bits4[q], nb4[q]);
-            pos += nb4[q];
+            put_bits_lds(s.wbuf[wv], rel, bits4[q], nb4[q]);
+            rel += nb4[q];
         }
+        wave_lds_fence();
+        for (uint32_t w = lane; w < nwords; w += 64) {
+            const uint32_t v = s.wbuf[wv][w];
+            s.wbuf[wv][w] = 0;
+            if (w == 0 || w + 1 == nwords) {
+                if (v) atomicOr(out32 + word0 + w, v);
+            } else {
+                out32[word0 + w] = v;
+            }
+        }
+        wave_lds_fence();
         bp += total;
         __syncthreads();
     }
