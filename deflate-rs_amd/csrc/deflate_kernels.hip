@@ -1117,6 +1117,7 @@ struct PackLds {
     uint16_t clc[20];
     uint8_t lll[288];
     uint8_t dl[32];
+    uint8_t cll[20];   // code-length code lengths of a dynamic block
     uint32_t scan[256];
     uint32_t carry;
     uint32_t wbuf[4][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
@@ -1195,28 +1196,40 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
     __syncthreads();
     if (tid == 0) canonical_codes(s.lll, 288, s.llc);  // huffman_table.rs:253-278
     if (tid == 64) canonical_codes(s.dl, 32, s.dc);
-    if (tid == 128 && pl.btype == BT_DYNAMIC) canonical_codes(h->cl_len, 19, s.clc);
+    if (tid == 128 && pl.btype == BT_DYNAMIC) canonical_codes(h->cl_len, 19, s.clc);  // (19 loads; the lists above are longer)
     __syncthreads();
     // block header
     uint32_t hdr_bits = 3;
     if (pl.btype == BT_DYNAMIC) {
-        // the header length follows from the plan: dyn_bits = header + body
+        // 3 + 14 bits, the code-length code lengths (huffman_lengths.rs:329-331), then the run-length
+        // coded lengths (:338-368), one symbol per thread: bit strings, a scan of their lengths over
+        // the workgroup, OR into the output.  (One lane walking the list would wait for two dependent
+        // loads from the header in global memory per symbol.)
+        const uint32_t used = h->used_hclens, n_enc = h->n_enc;
+        if (tid < 19) s.cll[tid] = h->cl_len[tid];
+        __syncthreads();
         if (tid == 0) {
             uint64_t p = bp;
             put_bits(out32, p, pl.bfinal ? 5u : 4u, 3);  // encoder_state.rs:12-13
             p += 3;
-            put_bits(out32, p, (h->n_ll - 257) | ((h->n_d - 1) << 5) | ((h->used_hclens >= 4 ? h->used_hclens - 4 : 0) << 10), 14);
+            put_bits(out32, p, (h->n_ll - 257) | ((h->n_d - 1) << 5) | ((used >= 4 ? used - 4 : 0) << 10), 14);
             p += 14;
-            for (uint32_t i = 0; i < h->used_hclens; i++) {  // huffman_lengths.rs:329-331
-                put_bits(out32, p, h->cl_len[hclen_order(i)], 3);
+            for (uint32_t i = 0; i < used; i++) {
+                put_bits(out32, p, s.cll[hclen_order(i)], 3);
                 p += 3;
             }
-            for (uint32_t i = 0; i < h->n_enc; i++) {  // :338-368
-                uint32_t e = h->enc[i], kind = e >> 8, v = e & 0xff;
-                uint32_t sym = el_symbol_index(e);
-                uint32_t cl = h->cl_len[sym];
-                uint64_t bits = s.clc[sym];
-                uint32_t nb2 = cl;
+        }
+        uint64_t hp = bp + 17 + 3ull * used;
+        const uint32_t lane0 = tid & 63, wv0 = tid >> 6;
+        for (uint32_t i0 = 0; i0 < n_enc; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            uint64_t bits = 0;
+            uint32_t nb2 = 0;
+            if (i < n_enc) {
+                const uint32_t e = h->enc[i], kind = e >> 8, v = e & 0xff;
+                const uint32_t sym = el_symbol_index(e);
+                nb2 = s.cll[sym];
+                bits = s.clc[sym];
                 if (kind == 1) {
                     bits |= (uint64_t)(v - 3) << nb2;
                     nb2 += 2;
@@ -1227,14 +1240,27 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
                     bits |= (uint64_t)(v - 11) << nb2;
                     nb2 += 7;
                 }
-                put_bits(out32, p, bits, nb2);
-                p += nb2;
             }
-            s.carry = (uint32_t)(p - bp);
+            uint32_t incl = nb2;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t y = __shfl_up(incl, off);
+                if (lane0 >= (uint32_t)off) incl += y;
+            }
+            if (lane0 == 63) s.scan[wv0] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                uint32_t y = s.scan[k];
+                if (k < wv0) wbase += y;
+                total += y;
+            }
+            put_bits(out32, hp + wbase + (incl - nb2), bits, nb2);
+            hp += total;
+            __syncthreads();
         }
-        __syncthreads();
-        hdr_bits = s.carry;
-        __syncthreads();
+        hdr_bits = (uint32_t)(hp - bp);
     } else if (tid == 0) {
         put_bits(out32, bp, pl.bfinal ? 3u : 2u, 3);  // encoder_state.rs:10-11
     }
