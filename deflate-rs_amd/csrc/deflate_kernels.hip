@@ -1056,7 +1056,9 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
                     n_dy++;
                 }
             }
-            uint32_t len_lo = __shfl((uint32_t)len, sidx), len_hi = __shfl((uint32_t)(len >> 32), sidx);
+            // (sidx is uniform: a scalar read of the lane, no trip through the LDS crossbar)
+            uint32_t len_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)len, (int)sidx),
+                     len_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(len >> 32), (int)sidx);
             bitpos += ((uint64_t)len_hi << 32) | len_lo;
         }
     }
