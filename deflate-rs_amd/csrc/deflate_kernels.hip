@@ -1028,8 +1028,47 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             my_sync = blk_sync[b];
             my_q13 = q13[b];
         }
-        // f(phase) for the 8 possible phases is tiny, but a plain in-order walk is enough here
         uint32_t cnt = nb - b0 < 64 ? nb - b0 : 64;
+        // Only the cost of a Stored block (and the pad of a sync marker) depends on the bit phase a block
+        // starts at.  A block whose type and length come out the same for all eight phases needs no
+        // walk: when that holds for all 64 blocks of the group, their bit offsets are a prefix sum.
+        bool fixed_len = have && my_sync == 0;
+        BlockPlan p0;
+        p0.btype = BT_FIXED;
+        p0.bfinal = 0;
+        p0.bit_start = 0;
+        p0.bit_len = 0;
+        if (have) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb && my_sync == 0, 0, &p0);
+        if (fixed_len) {
+#pragma unroll
+            for (uint32_t ph = 1; ph < 8; ph++) {
+                BlockPlan q;
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, false, ph, &q);
+                fixed_len = fixed_len && q.btype == p0.btype && q.bit_len == p0.bit_len;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(have && !fixed_len) == 0) {
+            const uint32_t mylen = have ? (uint32_t)p0.bit_len : 0u;  // < 2^21 for a non-stored block
+            uint32_t incl = mylen;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t y = __shfl_up(incl, off);
+                if (lane >= (uint32_t)off) incl += y;
+            }
+            if (have) {
+                p0.bit_start = bitpos + (incl - mylen);
+                plan[b] = p0;
+                if (p0.btype == BT_STORED) {  // (cannot happen here: a stored length depends on the phase)
+                    n_st++;
+                } else if (p0.btype == BT_FIXED) {
+                    n_fx++;
+                } else {
+                    n_dy++;
+                }
+            }
+            bitpos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            continue;
+        }
         for (uint32_t sidx = 0; sidx < cnt; sidx++) {
             uint64_t len = 0;
             if (lane == sidx) {
