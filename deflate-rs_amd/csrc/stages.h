@@ -521,6 +521,187 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
 #undef MI355_UNROLL
 }
 
+// ---- the same walk over hash-sorted positions (k_sort + k_match2) --------------------------------
+// Fourth formulation.  The positions of every 32 KiB epoch are sorted by (hash, position) -- S_e[0..J),
+// bucket h = S_e[B_e[h] .. B_e[h+1]) -- so the chain of matching.rs:124-132 for the entry j of bucket h
+// (position p) is S_e[j-1], S_e[j-2], ... down to B_e[h], then the bucket's entries of the previous
+// epoch from B_{e-1}[h+1]-1 downwards while they lie within 32768 of p: plain descending array reads
+// instead of a pointer chase, consecutive entries of a bucket (= consecutive lanes of a wave) read
+// consecutive addresses and have chains of nearly the same length.  A lane walks in RUNS: a run is a
+// stretch of one epoch's bucket cut to the budget left (max_hash_checks, and the quarter budget of
+// lz77.rs:351-355 while its result is still to be taken), so the common step only tests "index >= end
+// of run"; what is rare -- a probe hit (compare, matching.rs:141-156), the end of a run (take the
+// quarter result, go on in the previous epoch) -- parks the lane until the wave's next service.
+//
+// Index space of `W::sidx(i)`: i < 32768 = entry i of the previous epoch's array, i >= 32768 = entry
+// i - 32768 of the own epoch's; values are positions relative to their epoch.  Byte coordinates
+// (`W::load32`) are relative to the start of the previous epoch (of the own one for epoch 0):
+// `bias` = 32768 (0 for epoch 0) is the coordinate of the own epoch's first byte.
+enum : uint32_t { SW_OWN = 32768 };
+enum SwState : uint32_t { SW_WALK = 0, SW_PARK = 1, SW_RUNEND = 2, SW_DONE = 3 };
+
+template <bool HAS_Q>
+struct SortedLane {
+    uint32_t state;    // SwState
+    uint32_t prel;     // the searched position (byte coordinate)
+    uint32_t off;      // index of the candidate that is visited next
+    uint32_t endoff;   // last index of the current run
+    uint32_t cnext;    // sidx(off), read ahead
+    uint32_t bb;       // best_length - 1 + bias of the epoch the run is in: candidate value + bb = probe address
+    uint32_t lowa;     // probe addresses below this belong to candidates more than 32768 back (matching.rs:102-106)
+    uint32_t bm1;      // best_length - 1
+    uint32_t probe;    // bytes best-1, best of P (matching.rs:110,141)
+    uint32_t bestd;
+    uint32_t maxlen;   // matching.rs:112
+    uint32_t left;     // iterations left after the current run
+    uint32_t qleft;    // iterations left after the current run until the quarter result is taken
+    uint32_t range_lo; // lowest index of the bucket in the epoch the run is in
+    uint32_t pb0, pb1; // the bucket in the previous epoch: [pb0, pb1), empty when there is none
+    uint32_t bias;
+    uint32_t low;      // prel - 32768 (0 when that is negative): lowest candidate coordinate in reach
+    uint32_t mq;
+    uint32_t hq;       // quarter result taken
+    uint32_t acoord;   // probe address of the parked candidate
+    uint32_t in_prev;  // the run is in the previous epoch
+};
+
+// start a run from `off` downwards; false = nothing left to visit in this epoch's bucket or no budget
+template <bool HAS_Q, class W>
+MI355_HD bool sw_start_run(SortedLane<HAS_Q>& s, const W& w) {
+    if (s.off + 1 <= s.range_lo || s.left == 0) return false;  // (off + 1: off may be range_lo - 1)
+    uint32_t r = s.off + 1 - s.range_lo;
+    if (r > s.left) r = s.left;
+    if (HAS_Q && !s.hq && r > s.qleft) r = s.qleft;
+    if (r == 0) return false;
+    s.endoff = s.off + 1 - r;
+    s.left -= r;
+    if (HAS_Q && !s.hq) s.qleft -= r;
+    s.cnext = w.sidx(s.off);
+    s.state = SW_WALK;
+    return true;
+}
+
+// Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the
+// previous epoch (pb0 == pb1 for epoch 0).  prel / nrel: position and end of the visible data (byte
+// coordinates).  checks_q = 0 with HAS_Q: the quarter budget is zero iterations, its result empty.
+template <bool HAS_Q, class W>
+MI355_HD void sw_setup(SortedLane<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1,
+                       uint32_t prel, uint32_t nrel, uint32_t bias, uint32_t checks, uint32_t checks_q) {
+    s.prel = prel;
+    s.bias = bias;
+    s.low = prel > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : 0u;
+    s.bm1 = 0;
+    s.bestd = 0;
+    s.mq = 0;
+    s.hq = 0;
+    s.pb0 = pb0;
+    s.pb1 = pb1;
+    s.in_prev = 0;
+    s.acoord = 0;
+    s.cnext = 0;
+    s.endoff = 0;
+    s.left = checks;
+    s.qleft = checks_q;
+    if (HAS_Q && checks_q == 0) s.hq = 1;  // mq stays 0
+    s.range_lo = SW_OWN + own_b0;
+    s.off = SW_OWN + j - 1;
+    s.bb = bias;
+    s.lowa = s.low;
+    s.maxlen = 0;
+    s.probe = 0;
+    const bool search = prel + 2 < nrel && checks > 0;  // else no hash byte: never searched (lz77.rs:294-301)
+    if (!search) {
+        s.state = SW_DONE;
+        return;
+    }
+    const uint32_t left = nrel - prel;
+    s.maxlen = left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH;
+    s.probe = w.load32(prel) & 0xffffu;
+    s.state = SW_RUNEND;  // the first service starts the first run (own epoch, else the previous one)
+}
+
+// One chain step of a walking lane: matching.rs:124-143 for the candidate at `off`.
+template <bool HAS_Q, class W>
+MI355_HD void sw_step(SortedLane<HAS_Q>& s, const W& w) {
+    const uint32_t a = s.cnext + s.bb;
+    const uint32_t rv = w.load32(a) & 0xffffu;
+    if (a < s.lowa) {  // more than 32768 back, and so is everything after it
+        s.state = SW_DONE;
+    } else if (rv == s.probe) {
+        s.acoord = a;
+        s.state = SW_PARK;
+    } else {
+        const bool last = s.off == s.endoff;
+        s.off -= 1;  // (may wrap below index 0 at the end of a run; sw_start_run tests off + 1)
+        if (last)
+            s.state = SW_RUNEND;
+        else
+            s.cnext = w.sidx(s.off);
+    }
+}
+
+// Service of a lane that is not walking: the compare of a parked candidate (matching.rs:148-156),
+// then the run bookkeeping.  Leaves the lane walking or done.
+template <bool HAS_Q, class W>
+MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w) {
+    if (s.state == SW_PARK) {
+        const uint32_t c = s.acoord - s.bm1;  // byte coordinate of the candidate
+        uint32_t len = 0;                     // get_match_length matching.rs:67-72, eight bytes per round
+        while (len < s.maxlen) {
+            const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(c + len + 4)) << 32) |
+                               (uint64_t)(w.load32(s.prel + len) ^ w.load32(c + len));
+            if (x) {
+                len += (uint32_t)__builtin_ctzll(x) >> 3;
+                break;
+            }
+            len += 8;
+        }
+        if (len > s.maxlen) len = s.maxlen;
+        if (len > s.bm1 + 1) {  // matching.rs:149-156
+            const uint32_t ebias = s.bb - s.bm1;  // bias of the epoch the run is in
+            s.bm1 = len - 1;
+            s.bestd = s.prel - c;
+            s.bb = s.bm1 + ebias;
+            s.lowa = s.low + s.bm1;
+            if (len == s.maxlen) {
+                s.state = SW_DONE;
+                return;
+            }
+            s.probe = w.load32(s.prel + s.bm1) & 0xffffu;
+        }
+        const bool last = s.off == s.endoff;
+        s.off -= 1;
+        if (!last) {
+            s.cnext = w.sidx(s.off);
+            s.state = SW_WALK;
+            return;
+        }
+        s.state = SW_RUNEND;
+    }
+    if (s.state == SW_RUNEND) {
+        if (HAS_Q && !s.hq && s.qleft == 0) {  // lz77.rs:351-355: the state after max_hash_checks >> 2 iterations
+            s.mq = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
+            s.hq = 1;
+        }
+        if (sw_start_run(s, w)) return;
+        if (!s.in_prev && s.left > 0 && s.pb1 > s.pb0) {  // go on in the previous epoch's bucket
+            s.in_prev = 1;
+            s.range_lo = s.pb0;
+            s.off = s.pb1 - 1;
+            s.bb = s.bm1;  // bias 0
+            if (sw_start_run(s, w)) return;
+        }
+        s.state = SW_DONE;
+    }
+}
+
+template <bool HAS_Q>
+MI355_HD void sw_result(const SortedLane<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
+    const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
+    *m = r;
+    *mq = (HAS_Q && s.hq) ? s.mq : r;
+}
+
 // ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------
 // R[p] = number of bytes from p equal to data[p-1], capped at 258 and at the end of input; 0 if
 // p == 0 or data[p] != data[p-1].

@@ -51,9 +51,11 @@ struct Sim {
     std::vector<uint32_t> tokens;
     std::vector<uint64_t> tok_pos;
     int hier_mismatch = 0;
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr};  // what stage_links was given (mode 4 sorts by the same hashes)
 };
 
 void stage_links(Sim& s, const HashOverride& ov) {
+    s.ov = ov;
     s.link.assign(s.n + 1, 0);
     std::vector<int64_t> head(32768, -1);
     // identity-initialised head table (chained_hash_table.rs:64-69): matters only after a re-warm
@@ -79,6 +81,79 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
+    if (g_multi == 4) {
+        // the k_sort + k_match2 formulation: epochs sorted by (hash, position), lanes walk runs of the
+        // sorted arrays (stages.h SortedLane); step / service alternate as on the GPU
+        const uint32_t W = WINDOW_SIZE;
+        HostBytes by{s.in.data()};
+        bool hasq = s.cfg.use_quarter && cq != 0;
+        std::vector<uint16_t> prevS, curS;
+        std::vector<uint32_t> prevB(32769, 0), curB(32769, 0);
+        for (uint64_t E = 0; E < s.n; E += W) {
+            prevS.swap(curS);
+            prevB.swap(curB);
+            curS.clear();
+            std::vector<uint32_t> hs;
+            uint64_t hi = std::min<uint64_t>(s.n, E + W);
+            std::vector<uint32_t> order;
+            for (uint64_t p = E; p < hi; p++)
+                if (p + 2 < s.n) order.push_back((uint32_t)(p - E));
+            std::vector<uint32_t> hh(W, 0);
+            for (uint32_t r : order) hh[r] = position_hash(by, E + r, s.ov);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hh[a] < hh[b]; });
+            std::fill(curB.begin(), curB.end(), 0);
+            for (uint32_t r : order) curB[hh[r] + 1]++;
+            for (uint32_t h = 0; h < 32768; h++) curB[h + 1] += curB[h];
+            curS.assign(order.begin(), order.end());
+            struct Win {
+                const uint8_t* d;      // byte coordinate 0
+                const uint16_t* ps;    // previous epoch's array
+                const uint16_t* cs;    // own
+                uint32_t load32(uint32_t i) const {
+                    uint32_t v;
+                    memcpy(&v, d + i, 4);
+                    return v;
+                }
+                uint32_t sidx(uint32_t i) const { return i >= SW_OWN ? cs[i - SW_OWN] : ps[i]; }
+            };
+            const uint64_t wbase = E >= W ? E - W : 0;
+            const uint32_t bias = (uint32_t)(E - wbase);
+            Win win{s.in.data() + wbase, prevS.data(), curS.data()};
+            for (uint32_t j = 0; j < curS.size(); j++) {
+                const uint32_t r = curS[j], h = hh[r];
+                const uint32_t prel = bias + r, nrel = (uint32_t)(s.n - wbase);
+                uint32_t pb0 = 0, pb1 = 0;
+                if (E) {
+                    pb0 = prevB[h];
+                    pb1 = prevB[h + 1];
+                }
+                uint32_t m = 0, mq = 0;
+                auto run = [&](auto& ln) {
+                    sw_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, bias, s.cfg.checks, cq);
+                    uint32_t guard = 0;
+                    while (ln.state != SW_DONE) {
+                        for (int k = 0; k < 5; k++)
+                            if (ln.state == SW_WALK) sw_step(ln, win);
+                        if (ln.state != SW_WALK && ln.state != SW_DONE) sw_service(ln, win);
+                        if (++guard > 100000) break;
+                    }
+                    sw_result(ln, &m, &mq);
+                };
+                if (hasq) {
+                    SortedLane<true> ln;
+                    run(ln);
+                } else {
+                    SortedLane<false> ln;
+                    run(ln);
+                }
+                s.M[E + r] = m;
+                s.Mq[E + r] = mq;
+            }
+        }
+        if (s.cfg.use_quarter && cq == 0)
+            for (uint64_t p = 0; p < s.n; p++) s.Mq[p] = 0;
+        return;
+    }
     if (g_multi >= 2) {
         // the k_match formulation: parked extension, positions handed out by a shared counter
         struct Emit {
