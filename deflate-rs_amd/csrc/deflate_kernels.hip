@@ -424,6 +424,445 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sort + k_match2: the same longest_match table over hash-SORTED positions (stages.h SortedLane).
+//
+// k_sort (one workgroup per 32 KiB epoch) stands in for chained_hash_table.rs:118-158 as a whole: it
+// files every position of the epoch under its 15-bit hash, in position order -- S_e = the epoch's
+// positions sorted by (hash, position), B_e[h] = start of bucket h -- by a histogram (bucket starts)
+// and two stable counting-sort passes over the hash (low 8 bits, high 7 bits).  A pass ranks 64 keys
+// at a time: the lanes of a wave with the same digit find each other by ballots, the wave's running
+// digit offsets live in LDS, and every wave owns a contiguous sixteenth of the keys, so the order of
+// equal digits is kept.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t BSTRIDE = WINDOW_SIZE + 8;  // u16 entries per epoch in the bucket-start table (B[32768] = J)
+constexpr uint32_t SORT_CHUNK = WINDOW_SIZE / 16;  // keys per wave
+
+__device__ __forceinline__ uint32_t epoch_active(uint32_t n, uint64_t E) {  // positions of the epoch with a hash byte
+    const uint64_t act = n >= 2 ? (uint64_t)n - 2 : 0;
+    return act > E ? (uint32_t)((act - E) < (uint64_t)WINDOW_SIZE ? (act - E) : (uint64_t)WINDOW_SIZE) : 0u;
+}
+
+// exclusive prefix of one value per thread over a 1024-thread workgroup (two barriers inside)
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* red /*16*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= (uint32_t)off) x += y;
+    }
+    __syncthreads();  // (red may still be read from a previous call)
+    if (lane == 63) red[wv] = x;
+    __syncthreads();
+    uint32_t add = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t t = red[k];
+        add += k < wv ? t : 0u;
+        all += t;
+    }
+    if (total) *total = all;
+    return add + x - v;
+}
+
+// lanes of the wave that hold the same NB-bit digit as this lane (among `valid` lanes)
+template <int NB>
+__device__ __forceinline__ uint64_t wave_match(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const bool bit = (d >> b) & 1;
+        const uint64_t bal = __ballot(valid && bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+// one stable counting-sort pass of the workgroup: key i (i < J) has digit dig(i) < 2^NB and payload
+// pay(i); put(dest, payload) stores it at its rank
+template <int NB, class Dig, class Pay, class Put>
+__device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/, uint32_t* red, Dig dig, Pay pay, Put put) {
+    constexpr uint32_t ND = 1u << NB;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* mine = cnt + wv * 256;
+    for (uint32_t k = lane; k < 256; k += 64) mine[k] = 0;
+    wave_lds_fence();
+    const uint32_t cb = wv * SORT_CHUNK;
+    for (uint32_t b = 0; b < SORT_CHUNK; b += 64) {
+        const uint32_t i = cb + b + lane;
+        if (i < J) atomicAdd(&mine[dig(i)], 1u);
+    }
+    __syncthreads();
+    // offsets in (digit, wave) order: thread t takes digit t / 4, waves 4 * (t % 4) ..+3
+    uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+    const uint32_t d4 = tid >> 2, w4 = (tid & 3) * 4;
+    if (d4 < ND) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = cnt[(w4 + k) * 256 + d4];
+            sum += v[k];
+        }
+    }
+    uint32_t base = block_excl_scan_1024(sum, red, nullptr);
+    if (d4 < ND) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            cnt[(w4 + k) * 256 + d4] = base;
+            base += v[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < SORT_CHUNK; b += 64) {
+        const uint32_t i = cb + b + lane;
+        const bool valid = i < J;
+        const uint32_t d = valid ? dig(i) : 0u;
+        const uint64_t peers = wave_match<NB>(d, valid);
+        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        uint32_t at = 0;
+        if (valid) at = mine[d];
+        wave_lds_fence();  // every lane has read its offset before the last lane of each digit moves it on
+        if (valid) {
+            put(at + below, pay(i));
+            if (((peers >> lane) >> 1) == 0) mine[d] = at + (uint32_t)__popcll(peers);
+        }
+        wave_lds_fence();
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
+                                               uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0) {
+    __shared__ uint16_t sH[WINDOW_SIZE];
+    __shared__ __attribute__((aligned(16))) uint32_t sBuf[WINDOW_SIZE / 2];  // histogram (u16 pairs), then pass-1 output (u16)
+    __shared__ uint32_t sCnt[16 * 256];
+    __shared__ uint32_t sRed[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t e = e0 + blockIdx.x;
+    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
+    const uint32_t J = epoch_active(n, E);
+    for (uint32_t k = tid; k < WINDOW_SIZE / 2; k += 1024) sBuf[k] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < J; i += 1024) {
+        const uint64_t p = E + i;
+        uint32_t a, b, c;
+        if (n >= 4) {
+            const uint32_t v = load_u32_clamped(in, p, n);
+            a = v & 0xff;
+            b = (v >> 8) & 0xff;
+            c = (v >> 16) & 0xff;
+        } else {
+            a = in[p];
+            b = in[p + 1];
+            c = in[p + 2];
+        }
+        const uint32_t ab = rewarm_ab(ov, p, a, b);
+        const uint32_t h = hash3(ab & 0xff, ab >> 8, c);
+        sH[i] = (uint16_t)h;
+        atomicAdd(&sBuf[h >> 1], (h & 1) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    {   // bucket starts: thread t owns bins 32 t .. 32 t + 31
+        uint32_t wds[16], sum = 0;
+        const uint4* src = reinterpret_cast<const uint4*>(sBuf + tid * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 x = src[q];
+            wds[4 * q] = x.x;
+            wds[4 * q + 1] = x.y;
+            wds[4 * q + 2] = x.z;
+            wds[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) sum += (wds[q] & 0xffffu) + (wds[q] >> 16);
+        uint32_t run = block_excl_scan_1024(sum, sRed, nullptr);
+        uint32_t outw[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t lo = run;
+            run += wds[q] & 0xffffu;
+            const uint32_t hi = run;
+            run += wds[q] >> 16;
+            outw[q] = lo | (hi << 16);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(Bg + (size_t)e * BSTRIDE + tid * 32);
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
+        if (tid == 1023) Bg[(size_t)e * BSTRIDE + WINDOW_SIZE] = (uint16_t)J;
+    }
+    __syncthreads();
+    uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
+    sort_pass<8>(
+        J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
+        [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; });
+    uint16_t* out = Sg + (size_t)e * WINDOW_SIZE;
+    sort_pass<7>(
+        J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
+        [&](uint32_t at, uint32_t v) { out[at] = (uint16_t)v; });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match2: matching.rs:87-166 for the positions of one epoch, taken 64 at a time in the order of S_e
+// (so the lanes of a wave are neighbours in a hash bucket: their candidate lists are the same array
+// shifted by one, their reads of it coalesce, and their chains have nearly the same length).  LDS holds
+// the bytes of the previous and the own epoch (+ 258 lookahead); the sorted arrays are read from
+// global memory / L2 (a wave-step touches one or two lines of them).  Lanes walk in lockstep under the
+// execution mask; every M2_R steps the lanes that left the walk are serviced (stages.h sw_service).
+// ---------------------------------------------------------------------------------------------
+#ifndef MI355_M2_THREADS
+#define MI355_M2_THREADS 1024
+#endif
+#ifndef MI355_M2_R
+#define MI355_M2_R 6
+#endif
+constexpr uint32_t M2T = MI355_M2_THREADS;
+constexpr uint32_t M2_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
+
+struct SortWin {
+    const uint16_t* sb;   // global: index 0 = entry 0 of the previous epoch's sorted array
+    // byte coordinates are LDS addresses
+    __device__ uint32_t load32(uint32_t i) const {
+        typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
+        lds_u32 w = (lds_u32)(i & ~3u);
+        uint32_t lo = w[0], hi = w[1];
+        return __builtin_amdgcn_alignbyte(hi, lo, i);
+    }
+    // 16 bytes at any byte offset: five aligned dwords, four v_alignbyte
+    __device__ void load128(uint32_t i, uint32_t* q) const {
+        typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
+        lds_u32 w = (lds_u32)(i & ~3u);
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+        q[0] = __builtin_amdgcn_alignbyte(d1, d0, i);
+        q[1] = __builtin_amdgcn_alignbyte(d2, d1, i);
+        q[2] = __builtin_amdgcn_alignbyte(d3, d2, i);
+        q[3] = __builtin_amdgcn_alignbyte(d4, d3, i);
+    }
+    __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }  // (i may be -1: read ahead)
+};
+
+// M2_R chain steps (stages.h sw_step) for the lanes of `walk`, as one block of hand-scheduled code: the
+// lanes run under the execution mask, which only shrinks inside the block -- a lane whose candidate is
+// out of reach, passes the probe, or was the last of its run simply drops out and keeps its registers
+// for the service.  Per step: the candidate's probe bytes from LDS, the sorted array's entry two steps
+// ahead from global memory (three registers c / nx / nn rotate through the roles current, next, in
+// flight), three compares that write EXEC.  offb = 2 * off + 8 is the byte offset of the current
+// entry from sb8 = array base - 8 bytes (the offset register of a global load is unsigned).
+// Returns the lanes that are still walking.
+#define M2_STEP(C, N, L)                                \
+    "s_waitcnt vmcnt(1)\n\t"                            \
+    "v_add_u32_e32 %[a], " C ", %[bb]\n\t"              \
+    "ds_read_u8 %[t0], %[a]\n\t"                        \
+    "ds_read_u8 %[t1], %[a] offset:1\n\t"               \
+    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"            \
+    "global_load_ushort " L ", %[offb], %[sb] offset:-2\n\t" \
+    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"          \
+    "s_waitcnt lgkmcnt(0)\n\t"                          \
+    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"          \
+    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"        \
+    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"       \
+    "s_cbranch_execz .Lm2_end%=\n\t"
+static_assert(MI355_M2_R % 3 == 0, "the three read-ahead registers return to their roles every third step");
+
+__device__ __forceinline__ uint64_t m2_steps(uint32_t& c, uint32_t& nx, uint32_t& offb, uint32_t& a, uint32_t& rv,
+                                             uint32_t bb, uint32_t lowa, uint32_t probe, uint32_t endb,
+                                             const uint16_t* sb8, uint64_t walk) {
+    uint32_t nn, t1;
+    uint64_t save, still;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[walk]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        M2_STEP("%[c]", "%[nx]", "%[nn]")
+        M2_STEP("%[nx]", "%[nn]", "%[c]")
+        M2_STEP("%[nn]", "%[c]", "%[nx]")
+#if MI355_M2_R >= 6
+        M2_STEP("%[c]", "%[nx]", "%[nn]")
+        M2_STEP("%[nx]", "%[nn]", "%[c]")
+        M2_STEP("%[nn]", "%[c]", "%[nx]")
+#endif
+#if MI355_M2_R >= 9
+        M2_STEP("%[c]", "%[nx]", "%[nn]")
+        M2_STEP("%[nx]", "%[nn]", "%[c]")
+        M2_STEP("%[nn]", "%[c]", "%[nx]")
+#endif
+#if MI355_M2_R >= 12
+        M2_STEP("%[c]", "%[nx]", "%[nn]")
+        M2_STEP("%[nx]", "%[nn]", "%[c]")
+        M2_STEP("%[nn]", "%[c]", "%[nx]")
+#endif
+        ".Lm2_end%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 %[still], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [c] "+v"(c), [nx] "+v"(nx), [nn] "=&v"(nn), [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1),
+          [save] "=&s"(save), [still] "=&s"(still)
+        : [bb] "v"(bb), [lowa] "v"(lowa), [probe] "v"(probe), [endb] "v"(endb), [sb] "s"(sb8), [walk] "s"(walk)
+        : "vcc", "memory");
+    return still;
+}
+
+#ifdef MI355_MATCH_STATS
+#define M2_CNT(i, v) m2c[i] += (v);
+#define M2_T0 unsigned long long m2t = __builtin_readcyclecounter();
+#define M2_T(i)                                                    \
+    {                                                              \
+        unsigned long long t_ = __builtin_readcyclecounter();      \
+        m2c[i] += t_ - m2t;                                        \
+        m2t = t_;                                                  \
+    }
+#else
+#define M2_CNT(i, v)
+#define M2_T0
+#define M2_T(i)
+#endif
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
+                                                int in_aligned16, SegEnds sg, HashOverride ov, uint32_t e0,
+                                                uint32_t split) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_by[M2_BYTES];
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
+    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
+    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
+    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
+    if (in_aligned16) {
+        for (uint32_t w = tid; w < wbytes / 16; w += M2T) {
+            const uint64_t g = wbase + 16ull * w;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g + 16 <= n) {
+                v = *reinterpret_cast<const uint4*>(in + g);
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16; b++)
+                    if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            reinterpret_cast<uint4*>(s_by)[w] = v;
+        }
+    } else {
+        uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_by);
+        for (uint32_t w = tid; w < wbytes / 4; w += M2T) {
+            const uint64_t g = wbase + 4ull * w;
+            uint32_t v = 0;
+            for (int b = 0; b < 4; b++)
+                if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
+            sb32[w] = v;
+        }
+    }
+    const uint32_t J = epoch_active(n, E);
+    const uint32_t nbat = (J + 63) / 64;
+    const uint32_t b_lo = (uint32_t)((uint64_t)nbat * part / split), b_hi = (uint32_t)((uint64_t)nbat * (part + 1) / split);
+    if (tid == 0) s_next = b_lo;
+    if (part == 0 && tid < 2) {  // the positions without a hash byte (the last two of the input) are never searched
+        const uint64_t p = E + J + tid;
+        if (p < n && p < E + WINDOW_SIZE) {
+            M[p] = 0;
+            if (HAS_Q) Mq[p] = 0;
+        }
+    }
+    __syncthreads();
+    // byte coordinates = LDS addresses: org = the window's first byte, bias = the own epoch's first byte
+    const uint32_t org = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_by;
+    const uint32_t bias = org + (uint32_t)(E - wbase);
+    // (the array pointer may lie before the array for epoch 0; only indices >= 32768 - 2 are read then, and
+    // the array has a pad in front)
+    const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;
+    SortWin win{sbase};
+    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
+    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
+    const uint16_t* Bprev = Bown - BSTRIDE;
+    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
+#ifdef MI355_MATCH_STATS
+    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    M2_T0
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= b_hi) break;
+        const uint32_t j = b * 64 + lane;
+        const bool valid = j < J;
+        SortedLane<HAS_Q> st;
+        uint32_t srel = 0;
+        if (valid) {
+            srel = own[j];
+            const uint32_t prel = bias + srel;
+            const uint32_t v = win.load32(prel);
+            const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
+            const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
+            const uint32_t ob = Bown[h];
+            uint32_t pb0 = 0, pb1 = 0;
+            if (e) {
+                pb0 = Bprev[h];
+                pb1 = Bprev[h + 1];
+            }
+            sw_setup(st, win, j, ob, pb0, pb1, prel, org + lim(prel - org), org, bias, checks, checks_q);
+            if (st.state == SW_RUNEND) sw_service(st, win, org);  // the first run
+        } else {
+            st.state = SW_DONE;
+            st.bestd = 0;
+            st.bm1 = 0;
+            st.hq = 0;
+            st.mq = 0;
+            st.final = 1;
+        }
+        M2_CNT(0, 1)
+        M2_T(8)
+        for (;;) {
+            const bool pend0 = st.state == SW_PARK || st.state == SW_RUNEND;
+            if (__builtin_amdgcn_ballot_w64(pend0)) {
+                M2_CNT(2, 1)
+                M2_CNT(3, __popcll(__builtin_amdgcn_ballot_w64(pend0)))
+                if (pend0) sw_pending_fast(st, win, org);
+                M2_T(9)
+            }
+            const bool pend = st.state == SW_PARK || st.state == SW_RUNEND;
+            if (__builtin_amdgcn_ballot_w64(pend)) {
+                M2_CNT(4, 1)
+                M2_CNT(5, __popcll(__builtin_amdgcn_ballot_w64(st.state == SW_PARK)))
+                M2_CNT(6, __popcll(__builtin_amdgcn_ballot_w64(st.state == SW_RUNEND)))
+                if (pend) sw_service(st, win, org);
+                M2_T(10)
+            }
+            const uint64_t walk = __builtin_amdgcn_ballot_w64(st.state == SW_WALK);
+            if (walk == 0) {
+                if (__builtin_amdgcn_ballot_w64(st.state != SW_DONE) == 0) break;
+                continue;
+            }
+            uint32_t offb = st.off * 2 + 8, a = st.acoord, rv = 0, c = st.c, nx = st.nx;
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(walk))
+            M2_T(11)
+            const uint64_t still = m2_steps(c, nx, offb, a, rv, st.bb, st.lowa, st.probe, st.endoff * 2 + 8, sbase - 4, walk);
+            M2_T(12)
+            if (st.state == SW_WALK) {
+                st.off = (uint32_t)((int32_t)(offb - 8) >> 1);
+                st.c = c;
+                st.nx = nx;
+                st.acoord = a;
+                if (!__builtin_amdgcn_inverse_ballot_w64(still))
+                    st.state = a < st.lowa ? SW_DONE : (rv == st.probe ? SW_PARK : (st.final ? SW_DONE : SW_RUNEND));
+            }
+        }
+        if (valid) {
+            uint32_t m, mq;
+            sw_result(st, &m, &mq);
+            M[E + srel] = m;
+            if (HAS_Q) Mq[E + srel] = mq;
+        }
+        M2_T(13)
+    }
+#ifdef MI355_MATCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_rle: rle.rs:13-18 get_match_length_rle for every position: R[p] = run of data[p-1]
 // starting at p, capped at 258 and at the end of input.  Each lane owns 16 consecutive
 // positions: one forward scan of at most 258 bytes past its chunk, then a backward recurrence.

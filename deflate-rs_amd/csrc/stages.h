@@ -535,8 +535,8 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
 //
 // Index space of `W::sidx(i)`: i < 32768 = entry i of the previous epoch's array, i >= 32768 = entry
 // i - 32768 of the own epoch's; values are positions relative to their epoch.  Byte coordinates
-// (`W::load32`) are relative to the start of the previous epoch (of the own one for epoch 0):
-// `bias` = 32768 (0 for epoch 0) is the coordinate of the own epoch's first byte.
+// (`W::load32`): `org` = coordinate of the first byte of the previous epoch (of the own one for epoch
+// 0; an LDS address on the GPU, 0 on the host), `bias` = coordinate of the own epoch's first byte.
 enum : uint32_t { SW_OWN = 32768 };
 enum SwState : uint32_t { SW_WALK = 0, SW_PARK = 1, SW_RUNEND = 2, SW_DONE = 3 };
 
@@ -544,9 +544,9 @@ template <bool HAS_Q>
 struct SortedLane {
     uint32_t state;    // SwState
     uint32_t prel;     // the searched position (byte coordinate)
-    uint32_t off;      // index of the candidate that is visited next
+    uint32_t off;      // index of the candidate that is visited next (may wrap below 0 at the end of a run)
     uint32_t endoff;   // last index of the current run
-    uint32_t cnext;    // sidx(off), read ahead
+    uint32_t c, nx;    // walking: sidx(off) and sidx(off - 1), read ahead
     uint32_t bb;       // best_length - 1 + bias of the epoch the run is in: candidate value + bb = probe address
     uint32_t lowa;     // probe addresses below this belong to candidates more than 32768 back (matching.rs:102-106)
     uint32_t bm1;      // best_length - 1
@@ -557,18 +557,19 @@ struct SortedLane {
     uint32_t qleft;    // iterations left after the current run until the quarter result is taken
     uint32_t range_lo; // lowest index of the bucket in the epoch the run is in
     uint32_t pb0, pb1; // the bucket in the previous epoch: [pb0, pb1), empty when there is none
-    uint32_t bias;
-    uint32_t low;      // prel - 32768 (0 when that is negative): lowest candidate coordinate in reach
+    uint32_t low;      // prel - 32768 (coordinate 0 when that is negative): lowest candidate coordinate in reach
     uint32_t mq;
     uint32_t hq;       // quarter result taken
     uint32_t acoord;   // probe address of the parked candidate
     uint32_t in_prev;  // the run is in the previous epoch
+    uint32_t final;    // nothing can follow the current run
+    uint32_t p16[4];   // the first 16 bytes of P (sw_park_fast)
 };
 
 // start a run from `off` downwards; false = nothing left to visit in this epoch's bucket or no budget
 template <bool HAS_Q, class W>
 MI355_HD bool sw_start_run(SortedLane<HAS_Q>& s, const W& w) {
-    if (s.off + 1 <= s.range_lo || s.left == 0) return false;  // (off + 1: off may be range_lo - 1)
+    if ((int32_t)s.off < (int32_t)s.range_lo || s.left == 0) return false;
     uint32_t r = s.off + 1 - s.range_lo;
     if (r > s.left) r = s.left;
     if (HAS_Q && !s.hq && r > s.qleft) r = s.qleft;
@@ -576,20 +577,24 @@ MI355_HD bool sw_start_run(SortedLane<HAS_Q>& s, const W& w) {
     s.endoff = s.off + 1 - r;
     s.left -= r;
     if (HAS_Q && !s.hq) s.qleft -= r;
-    s.cnext = w.sidx(s.off);
+    s.c = w.sidx(s.off);
+    s.nx = w.sidx(s.off - 1);
     s.state = SW_WALK;
+    // (a quarter result that falls due at the end of the last run equals the final result)
+    s.final = !(s.left > 0 && (s.endoff > s.range_lo || (!s.in_prev && s.pb1 > s.pb0)));
     return true;
 }
 
 // Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the
-// previous epoch (pb0 == pb1 for epoch 0).  prel / nrel: position and end of the visible data (byte
-// coordinates).  checks_q = 0 with HAS_Q: the quarter budget is zero iterations, its result empty.
+// previous epoch (pb0 == pb1 for epoch 0).  prel / nrel: position and end of the visible data, `org` =
+// coordinate of the first byte of the previous epoch (of the own one for epoch 0), `bias` = coordinate
+// of the own epoch's first byte.  checks_q = 0 with HAS_Q: the quarter budget is zero iterations, its
+// result empty.
 template <bool HAS_Q, class W>
 MI355_HD void sw_setup(SortedLane<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1,
-                       uint32_t prel, uint32_t nrel, uint32_t bias, uint32_t checks, uint32_t checks_q) {
+                       uint32_t prel, uint32_t nrel, uint32_t org, uint32_t bias, uint32_t checks, uint32_t checks_q) {
     s.prel = prel;
-    s.bias = bias;
-    s.low = prel > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : 0u;
+    s.low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
     s.bm1 = 0;
     s.bestd = 0;
     s.mq = 0;
@@ -597,8 +602,10 @@ MI355_HD void sw_setup(SortedLane<HAS_Q>& s, const W& w, uint32_t j, uint32_t ow
     s.pb0 = pb0;
     s.pb1 = pb1;
     s.in_prev = 0;
+    s.final = 0;
     s.acoord = 0;
-    s.cnext = 0;
+    s.c = 0;
+    s.nx = 0;
     s.endoff = 0;
     s.left = checks;
     s.qleft = checks_q;
@@ -616,34 +623,88 @@ MI355_HD void sw_setup(SortedLane<HAS_Q>& s, const W& w, uint32_t j, uint32_t ow
     }
     const uint32_t left = nrel - prel;
     s.maxlen = left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH;
-    s.probe = w.load32(prel) & 0xffffu;
+    w.load128(prel, s.p16);
+    s.probe = s.p16[0] & 0xffffu;
     s.state = SW_RUNEND;  // the first service starts the first run (own epoch, else the previous one)
 }
 
-// One chain step of a walking lane: matching.rs:124-143 for the candidate at `off`.
+// One chain step of a walking lane: matching.rs:124-143 for the candidate at `off`.  (k_match2 runs
+// these steps as hand-scheduled code under the execution mask; the order of the tests is the same.)
 template <bool HAS_Q, class W>
 MI355_HD void sw_step(SortedLane<HAS_Q>& s, const W& w) {
-    const uint32_t a = s.cnext + s.bb;
+    const uint32_t a = s.c + s.bb;
     const uint32_t rv = w.load32(a) & 0xffffu;
+    s.off -= 1;
+    s.acoord = a;
     if (a < s.lowa) {  // more than 32768 back, and so is everything after it
         s.state = SW_DONE;
     } else if (rv == s.probe) {
-        s.acoord = a;
         s.state = SW_PARK;
+    } else if ((int32_t)s.off < (int32_t)s.endoff) {
+        s.state = s.final ? SW_DONE : SW_RUNEND;
     } else {
-        const bool last = s.off == s.endoff;
-        s.off -= 1;  // (may wrap below index 0 at the end of a run; sw_start_run tests off + 1)
-        if (last)
-            s.state = SW_RUNEND;
+        s.c = s.nx;
+        s.nx = w.sidx(s.off - 1);
+    }
+}
+
+// The common cases of the service as straight-line code.  A parked lane whose candidate differs from
+// P within 16 bytes: matching.rs:148-156, then on to the next candidate of the run.  A lane at the end
+// of its run in the own epoch with budget left and no quarter result pending: on to the bucket of the
+// previous epoch.  Lanes in any other situation keep their state for sw_service.
+template <bool HAS_Q, class W>
+MI355_HD void sw_pending_fast(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
+    bool resume = false;
+    if (s.state == SW_PARK) {
+        const uint32_t c = s.acoord - s.bm1;
+        uint32_t q[4];
+        w.load128(c, q);
+        const uint64_t z0 = ((uint64_t)(q[1] ^ s.p16[1]) << 32) | (uint64_t)(q[0] ^ s.p16[0]);
+        const uint64_t z1 = ((uint64_t)(q[3] ^ s.p16[3]) << 32) | (uint64_t)(q[2] ^ s.p16[2]);
+        uint32_t len = z0 ? ((uint32_t)__builtin_ctzll(z0) >> 3) : (z1 ? 8u + ((uint32_t)__builtin_ctzll(z1) >> 3) : 16u);
+        if (len == 16 && s.maxlen > 16) return;
+        if (len > s.maxlen) len = s.maxlen;
+        if (len > s.bm1 + 1) {
+            const uint32_t ebias = s.bb - s.bm1;
+            s.bm1 = len - 1;
+            s.bestd = s.prel - c;
+            s.bb = s.bm1 + ebias;
+            s.lowa = s.low + s.bm1;
+            if (len == s.maxlen) {
+                s.state = SW_DONE;
+                return;
+            }
+            s.probe = w.load32(s.prel + s.bm1) & 0xffffu;
+        }
+        if ((int32_t)s.off >= (int32_t)s.endoff)
+            resume = true;
         else
-            s.cnext = w.sidx(s.off);
+            s.state = s.final ? SW_DONE : SW_RUNEND;
+    }
+    if (s.state == SW_RUNEND && (!HAS_Q || s.hq) && !s.in_prev && (int32_t)s.off < (int32_t)s.range_lo) {
+        // (not final: budget is left and the previous epoch's bucket has entries)
+        s.in_prev = 1;
+        s.range_lo = s.pb0;
+        s.off = s.pb1 - 1;
+        s.bb = s.bm1 + org;
+        uint32_t r = s.pb1 - s.pb0;
+        if (r > s.left) r = s.left;
+        s.endoff = s.off + 1 - r;
+        s.left -= r;
+        s.final = 1;
+        resume = true;
+    }
+    if (resume) {
+        s.c = w.sidx(s.off);
+        s.nx = w.sidx(s.off - 1);
+        s.state = SW_WALK;
     }
 }
 
 // Service of a lane that is not walking: the compare of a parked candidate (matching.rs:148-156),
 // then the run bookkeeping.  Leaves the lane walking or done.
 template <bool HAS_Q, class W>
-MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w) {
+MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
     if (s.state == SW_PARK) {
         const uint32_t c = s.acoord - s.bm1;  // byte coordinate of the candidate
         uint32_t len = 0;                     // get_match_length matching.rs:67-72, eight bytes per round
@@ -669,14 +730,13 @@ MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w) {
             }
             s.probe = w.load32(s.prel + s.bm1) & 0xffffu;
         }
-        const bool last = s.off == s.endoff;
-        s.off -= 1;
-        if (!last) {
-            s.cnext = w.sidx(s.off);
+        if ((int32_t)s.off >= (int32_t)s.endoff) {
+            s.c = w.sidx(s.off);
+            s.nx = w.sidx(s.off - 1);
             s.state = SW_WALK;
             return;
         }
-        s.state = SW_RUNEND;
+        s.state = s.final ? SW_DONE : SW_RUNEND;
     }
     if (s.state == SW_RUNEND) {
         if (HAS_Q && !s.hq && s.qleft == 0) {  // lz77.rs:351-355: the state after max_hash_checks >> 2 iterations
@@ -688,7 +748,7 @@ MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w) {
             s.in_prev = 1;
             s.range_lo = s.pb0;
             s.off = s.pb1 - 1;
-            s.bb = s.bm1;  // bias 0
+            s.bb = s.bm1 + org;  // the previous epoch's values count from the origin
             if (sw_start_run(s, w)) return;
         }
         s.state = SW_DONE;

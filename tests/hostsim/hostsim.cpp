@@ -114,11 +114,16 @@ void stage_match(Sim& s) {
                     memcpy(&v, d + i, 4);
                     return v;
                 }
-                uint32_t sidx(uint32_t i) const { return i >= SW_OWN ? cs[i - SW_OWN] : ps[i]; }
+                void load128(uint32_t i, uint32_t* q) const { memcpy(q, d + i, 16); }
+                uint32_t np, nc;       // entries in the two arrays (reads ahead of a run's end may fall outside)
+                uint32_t sidx(uint32_t i) const {
+                    if (i >= SW_OWN) return i - SW_OWN < nc ? cs[i - SW_OWN] : 0u;
+                    return i < np ? ps[i] : 0u;
+                }
             };
             const uint64_t wbase = E >= W ? E - W : 0;
             const uint32_t bias = (uint32_t)(E - wbase);
-            Win win{s.in.data() + wbase, prevS.data(), curS.data()};
+            Win win{s.in.data() + wbase, prevS.data(), curS.data(), (uint32_t)prevS.size(), (uint32_t)curS.size()};
             for (uint32_t j = 0; j < curS.size(); j++) {
                 const uint32_t r = curS[j], h = hh[r];
                 const uint32_t prel = bias + r, nrel = (uint32_t)(s.n - wbase);
@@ -129,12 +134,14 @@ void stage_match(Sim& s) {
                 }
                 uint32_t m = 0, mq = 0;
                 auto run = [&](auto& ln) {
-                    sw_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, bias, s.cfg.checks, cq);
+                    sw_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
                     uint32_t guard = 0;
                     while (ln.state != SW_DONE) {
                         for (int k = 0; k < 5; k++)
                             if (ln.state == SW_WALK) sw_step(ln, win);
-                        if (ln.state != SW_WALK && ln.state != SW_DONE) sw_service(ln, win);
+                        if (ln.state != SW_WALK && ln.state != SW_DONE && (guard & 1))
+                            sw_pending_fast(ln, win, 0u);  // (every other time: both paths run)
+                        if (ln.state != SW_WALK && ln.state != SW_DONE) sw_service(ln, win, 0u);
                         if (++guard > 100000) break;
                     }
                     sw_result(ln, &m, &mq);

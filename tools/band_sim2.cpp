@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     size_t maxb = argc > 3 ? strtoull(argv[3], 0, 10) : (size_t)8000000;
     uint32_t R = argc > 4 ? atoi(argv[4]) : 8;
     int sort_by_cnt = argc > 5 ? atoi(argv[5]) : 0;
+    uint32_t TH = argc > 6 ? atoi(argv[6]) : 1;  // service only when at least TH lanes wait (or none walks)
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 1;
     std::vector<uint8_t> d(maxb + 8);
@@ -97,7 +98,9 @@ int main(int argc, char** argv) {
                         }
                     }
                 }
-                bool serv = !anyw || (step % R) == 0;
+                uint32_t npend = 0;
+                for (uint32_t l = 0; l < nl; l++) npend += state[l] == 1;
+                bool serv = !anyw || ((step % R) == 0 && npend >= TH);
                 if (!serv) continue;
                 uint32_t np = 0, mr = 0;
                 for (uint32_t l = 0; l < nl; l++) {
@@ -121,9 +124,9 @@ int main(int argc, char** argv) {
     }
     printf("positions %llu visits/pos %.2f batches %llu\n", (unsigned long long)positions, (double)visits / positions,
            (unsigned long long)batches);
-    printf("R=%u sort=%d: wave-steps/batch %.2f (walking-lane share %.3f), services/batch %.2f, parked lanes/service %.1f, "
+    printf("R=%u TH=%u sort=%d: wave-steps/batch %.2f (walking-lane share %.3f), services/batch %.2f, parked lanes/service %.1f, "
            "8-byte compare rounds/service %.2f, first-compare rounds/batch %.2f\n",
-           R, sort_by_cnt, (double)wave_steps / batches, (double)walking_slots / (64.0 * wave_steps), (double)services / batches,
+           R, TH, sort_by_cnt, (double)wave_steps / batches, (double)walking_slots / (64.0 * wave_steps), (double)services / batches,
            (double)parked_serv / services, (double)cmp_rounds / services, (double)first_rounds / batches);
     double instr = (double)wave_steps * 8 + (double)services * (25 + 0) + (double)cmp_rounds * 14 + batches * (60.0) + first_rounds * 14.0;
     printf("model: %.1f wave-instructions per position (8/step, 25+14/round per service, 60+14/round setup)\n", instr / positions);
