@@ -612,7 +612,7 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 #define MI355_M2_THREADS 1024
 #endif
 #ifndef MI355_M2_R
-#define MI355_M2_R 6
+#define MI355_M2_R 12
 #endif
 constexpr uint32_t M2T = MI355_M2_THREADS;
 constexpr uint32_t M2_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
@@ -662,15 +662,15 @@ struct SortWin {
     "s_cbranch_execz .Lm2_end%=\n\t"
 static_assert(MI355_M2_R % 3 == 0, "the three read-ahead registers return to their roles every third step");
 
-__device__ __forceinline__ uint64_t m2_steps(uint32_t& c, uint32_t& nx, uint32_t& offb, uint32_t& a, uint32_t& rv,
-                                             uint32_t bb, uint32_t lowa, uint32_t probe, uint32_t endb,
-                                             const uint16_t* sb8, uint64_t walk) {
-    uint32_t nn, t1;
+__device__ __forceinline__ uint64_t m2_steps(uint32_t& offb, uint32_t& a, uint32_t& rv, uint32_t bb, uint32_t lowa,
+                                             uint32_t probe, uint32_t endb, const uint16_t* sb8, uint64_t walk) {
+    uint32_t c, nx, nn, t1;
     uint64_t save, still;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "s_mov_b64 exec, %[walk]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
+        "global_load_ushort %[c], %[offb], %[sb]\n\t"
+        "global_load_ushort %[nx], %[offb], %[sb] offset:-2\n\t"
         M2_STEP("%[c]", "%[nx]", "%[nn]")
         M2_STEP("%[nx]", "%[nn]", "%[c]")
         M2_STEP("%[nn]", "%[c]", "%[nx]")
@@ -693,7 +693,7 @@ __device__ __forceinline__ uint64_t m2_steps(uint32_t& c, uint32_t& nx, uint32_t
         "s_waitcnt vmcnt(0)\n\t"
         "s_mov_b64 %[still], exec\n\t"
         "s_mov_b64 exec, %[save]\n\t"
-        : [c] "+v"(c), [nx] "+v"(nx), [nn] "=&v"(nn), [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1),
+        : [c] "=&v"(c), [nx] "=&v"(nx), [nn] "=&v"(nn), [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1),
           [save] "=&s"(save), [still] "=&s"(still)
         : [bb] "v"(bb), [lowa] "v"(lowa), [probe] "v"(probe), [endb] "v"(endb), [sb] "s"(sb8), [walk] "s"(walk)
         : "vcc", "memory");
@@ -786,8 +786,9 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         if (b >= b_hi) break;
         const uint32_t j = b * 64 + lane;
         const bool valid = j < J;
-        SortedLane<HAS_Q> st;
+        SwLean<HAS_Q> st;
         uint32_t srel = 0;
+        bool search = false;
         if (valid) {
             srel = own[j];
             const uint32_t prel = bias + srel;
@@ -800,57 +801,29 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
                 pb0 = Bprev[h];
                 pb1 = Bprev[h + 1];
             }
-            sw_setup(st, win, j, ob, pb0, pb1, prel, org + lim(prel - org), org, bias, checks, checks_q);
-            if (st.state == SW_RUNEND) sw_service(st, win, org);  // the first run
+            search = swl_setup(st, win, j, ob, pb0, pb1, prel, org + lim(prel - org), org, bias, checks, checks_q);
         } else {
-            st.state = SW_DONE;
-            st.bestd = 0;
-            st.bm1 = 0;
-            st.hq = 0;
-            st.mq = 0;
-            st.final = 1;
+            (void)swl_setup(st, win, 0u, 0u, 0u, 0u, bias, bias, org, bias, checks, checks_q);
         }
+        const uint64_t start = __builtin_amdgcn_ballot_w64(search);
+        st.done = ~start;
+        swl_service(st, win, org, (uint64_t)0, start);
         M2_CNT(0, 1)
         M2_T(8)
         for (;;) {
-            const bool pend0 = st.state == SW_PARK || st.state == SW_RUNEND;
-            if (__builtin_amdgcn_ballot_w64(pend0)) {
-                M2_CNT(2, 1)
-                M2_CNT(3, __popcll(__builtin_amdgcn_ballot_w64(pend0)))
-                if (pend0) sw_pending_fast(st, win, org);
-                M2_T(9)
-            }
-            const bool pend = st.state == SW_PARK || st.state == SW_RUNEND;
-            if (__builtin_amdgcn_ballot_w64(pend)) {
-                M2_CNT(4, 1)
-                M2_CNT(5, __popcll(__builtin_amdgcn_ballot_w64(st.state == SW_PARK)))
-                M2_CNT(6, __popcll(__builtin_amdgcn_ballot_w64(st.state == SW_RUNEND)))
-                if (pend) sw_service(st, win, org);
-                M2_T(10)
-            }
-            const uint64_t walk = __builtin_amdgcn_ballot_w64(st.state == SW_WALK);
-            if (walk == 0) {
-                if (__builtin_amdgcn_ballot_w64(st.state != SW_DONE) == 0) break;
-                continue;
-            }
-            uint32_t offb = st.off * 2 + 8, a = st.acoord, rv = 0, c = st.c, nx = st.nx;
+            const uint64_t walk = st.walk;
+            if (walk == 0) break;
             M2_CNT(1, 1)
             M2_CNT(7, __popcll(walk))
-            M2_T(11)
-            const uint64_t still = m2_steps(c, nx, offb, a, rv, st.bb, st.lowa, st.probe, st.endoff * 2 + 8, sbase - 4, walk);
+            const uint64_t still = m2_steps(st.offb, st.a, st.rv, st.bb, st.lowa, st.probe, st.endb, sbase - 4, walk);
             M2_T(12)
-            if (st.state == SW_WALK) {
-                st.off = (uint32_t)((int32_t)(offb - 8) >> 1);
-                st.c = c;
-                st.nx = nx;
-                st.acoord = a;
-                if (!__builtin_amdgcn_inverse_ballot_w64(still))
-                    st.state = a < st.lowa ? SW_DONE : (rv == st.probe ? SW_PARK : (st.final ? SW_DONE : SW_RUNEND));
-            }
+            st.walk = still;
+            swl_service(st, win, org, walk & ~still, (uint64_t)0);
+            M2_T(9)
         }
         if (valid) {
             uint32_t m, mq;
-            sw_result(st, &m, &mq);
+            swl_result(st, &m, &mq);
             M[E + srel] = m;
             if (HAS_Q) Mq[E + srel] = mq;
         }

@@ -648,10 +648,11 @@ MI355_HD void sw_step(SortedLane<HAS_Q>& s, const W& w) {
     }
 }
 
-// The common cases of the service as straight-line code.  A parked lane whose candidate differs from
-// P within 16 bytes: matching.rs:148-156, then on to the next candidate of the run.  A lane at the end
+// The service as it runs on the GPU: straight-line for the common cases.  A parked lane: the candidate
+// against 16 bytes of P kept in registers (a loop only beyond those), matching.rs:148-156, then on to the
+// next candidate of the run.  A lane at the end
 // of its run in the own epoch with budget left and no quarter result pending: on to the bucket of the
-// previous epoch.  Lanes in any other situation keep their state for sw_service.
+// previous epoch.  Only a lane that has to take the quarter result first keeps its state for sw_service.
 template <bool HAS_Q, class W>
 MI355_HD void sw_pending_fast(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
     bool resume = false;
@@ -662,7 +663,17 @@ MI355_HD void sw_pending_fast(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
         const uint64_t z0 = ((uint64_t)(q[1] ^ s.p16[1]) << 32) | (uint64_t)(q[0] ^ s.p16[0]);
         const uint64_t z1 = ((uint64_t)(q[3] ^ s.p16[3]) << 32) | (uint64_t)(q[2] ^ s.p16[2]);
         uint32_t len = z0 ? ((uint32_t)__builtin_ctzll(z0) >> 3) : (z1 ? 8u + ((uint32_t)__builtin_ctzll(z1) >> 3) : 16u);
-        if (len == 16 && s.maxlen > 16) return;
+        if (len == 16) {  // the rare long match: eight more bytes per round
+            while (len < s.maxlen) {
+                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(c + len + 4)) << 32) |
+                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(c + len));
+                if (x) {
+                    len += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                len += 8;
+            }
+        }
         if (len > s.maxlen) len = s.maxlen;
         if (len > s.bm1 + 1) {
             const uint32_t ebias = s.bb - s.bm1;
@@ -760,6 +771,168 @@ MI355_HD void sw_result(const SortedLane<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
     const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
     *m = r;
     *mq = (HAS_Q && s.hq) ? s.mq : r;
+}
+
+// ---- the sorted walk as the GPU runs it (k_match2): predicated, one service per block of steps ---------
+// Same lists, same runs and the same tests as SortedLane above, reshaped for a wave: per-lane flags are
+// lane masks (lane_flag), the step block (swl_steps_ref here, hand-scheduled code under the execution
+// mask on the GPU) takes R steps for the walking lanes, and ONE straight-line service then settles every
+// lane that dropped out of the block -- compare, result update, end of run, move to the previous epoch's
+// bucket -- by selects, so that a lane is either walking or done between blocks.  Indices are kept as byte
+// offsets: offb = 2 * index + 8 (the form the GPU's loads want), lob / lob2 = offset of the first entry of
+// the bucket in the own / previous epoch's part, offb2 = offset of the previous epoch's last bucket entry.
+template <bool HAS_Q>
+struct SwLean {
+    uint32_t offb, endb, c, nx, a, rv, bb, lowa, probe;  // the registers of the step block
+    uint32_t bm1, bestd, prel, maxlen, low, p16[4];
+    uint32_t lob, offb2, lob2, left, qleft, mq;
+    lane_flag walk, done, in_prev, final, hq;
+};
+
+MI355_HD lane_flag lf_and_not(lane_flag a, lane_flag b) { return a & lf_not(b); }
+
+// R chain steps of a walking lane (host twin of the GPU's step block; the order of the tests is the GPU's):
+// window, probe, end of run.  A lane that drops out keeps a / rv of its last candidate; offb already
+// points at the entry after it.
+template <bool HAS_Q, class W>
+MI355_HD void swl_steps_ref(SwLean<HAS_Q>& s, const W& w, uint32_t R) {
+    if (!lf_me(s.walk)) return;
+    s.c = w.sidx((uint32_t)((int32_t)(s.offb - 8) >> 1));
+    s.nx = w.sidx((uint32_t)((int32_t)(s.offb - 10) >> 1));
+    for (uint32_t k = 0; k < R; k++) {
+        s.a = s.c + s.bb;
+        s.rv = w.load32(s.a) & 0xffffu;
+        s.offb -= 2;
+        if (s.a < s.lowa || s.rv == s.probe || (int32_t)s.offb < (int32_t)s.endb) {
+            s.walk = lf_of(false);
+            return;
+        }
+        s.c = s.nx;
+        s.nx = w.sidx((uint32_t)((int32_t)(s.offb - 10) >> 1));
+    }
+}
+
+// Settle the lanes that left the last block (`dropped`) and the lanes that have not started yet (`start`:
+// their first run begins).  Straight-line selects; only a match longer than 16 bytes loops.
+template <bool HAS_Q, class W>
+MI355_HD void swl_service(SwLean<HAS_Q>& s, const W& w, uint32_t org, lane_flag dropped, lane_flag start) {
+    const lane_flag out = dropped & lf_of(s.a < s.lowa);                      // matching.rs:102-106,127
+    const lane_flag hit = lf_and_not(dropped, out) & lf_of(s.rv == s.probe);  // matching.rs:141-143
+    lane_flag rend = lf_and_not(lf_and_not(dropped, out), hit) | start;
+    // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
+    const uint32_t cpos = s.a - s.bm1;
+    uint32_t q[4];
+    w.load128(cpos, q);
+    // first differing bit of the 128: ffs - 1 is all ones for a zero word, which the OR keeps largest
+    const uint32_t b0 = (uint32_t)(__builtin_ffs((int)(q[0] ^ s.p16[0])) - 1);
+    const uint32_t b1 = (uint32_t)(__builtin_ffs((int)(q[1] ^ s.p16[1])) - 1) | 32u;
+    const uint32_t b2 = (uint32_t)(__builtin_ffs((int)(q[2] ^ s.p16[2])) - 1) | 64u;
+    const uint32_t b3 = (uint32_t)(__builtin_ffs((int)(q[3] ^ s.p16[3])) - 1) | 96u;
+    uint32_t bits = b0 < b1 ? b0 : b1;
+    const uint32_t bh = b2 < b3 ? b2 : b3;
+    bits = bits < bh ? bits : bh;
+    uint32_t len = (bits < 128u ? bits : 128u) >> 3;
+    const lane_flag lng = hit & lf_of(len == 16 && s.maxlen > 16);
+    if (lf_any(lng)) {
+        if (lf_me(lng)) {
+            while (len < s.maxlen) {
+                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(cpos + len + 4)) << 32) |
+                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(cpos + len));
+                if (x) {
+                    len += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                len += 8;
+            }
+        }
+    }
+    len = len < s.maxlen ? len : s.maxlen;
+    const lane_flag imp = hit & lf_of(len > s.bm1 + 1);  // matching.rs:149-156
+    const uint32_t delta = lf_me(imp) ? len - 1 - s.bm1 : 0u;
+    s.bestd = lf_me(imp) ? s.prel - cpos : s.bestd;
+    s.bm1 += delta;
+    s.bb += delta;
+    s.lowa += delta;
+    const lane_flag full = imp & lf_of(len == s.maxlen);
+    const uint32_t pr = w.load32(s.prel + s.bm1) & 0xffffu;
+    s.probe = lf_me(imp) ? pr : s.probe;
+    const lane_flag more = lf_of((int32_t)s.offb >= (int32_t)s.endb);
+    const lane_flag hgo = lf_and_not(hit, full);
+    rend = rend | lf_and_not(hgo, more);
+    const lane_flag resume = hgo & more;
+    s.done = s.done | out | full | (lf_and_not(rend, start) & s.final);
+    rend = lf_and_not(rend, lf_and_not(s.final, start));
+    // end of a run that is not the last one (sw_service above): the quarter result, then the rest of the
+    // bucket, else the bucket of the previous epoch
+    if (HAS_Q) {
+        const lane_flag cap = lf_and_not(rend, s.hq) & lf_of(s.qleft == 0);  // lz77.rs:351-355
+        s.mq = lf_me(cap) ? m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd) : s.mq;
+        s.hq = s.hq | cap;
+    }
+    const int32_t av1 = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
+    const lane_flag same = rend & lf_of(av1 > 0 && s.left > 0);
+    const lane_flag sw =
+        lf_and_not(lf_and_not(rend, same), s.in_prev) & lf_of(s.left > 0 && (int32_t)s.offb2 >= (int32_t)s.lob2);
+    s.done = s.done | lf_and_not(lf_and_not(rend, same), sw);
+    s.offb = lf_me(sw) ? s.offb2 : s.offb;
+    s.lob = lf_me(sw) ? s.lob2 : s.lob;
+    s.bb = lf_me(sw) ? s.bm1 + org : s.bb;
+    s.in_prev = s.in_prev | sw;
+    const lane_flag go = same | sw;
+    const int32_t av = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
+    uint32_t r = (uint32_t)av < s.left ? (uint32_t)av : s.left;
+    if (HAS_Q) r = (lf_me(s.hq) || r < s.qleft) ? r : s.qleft;
+    r = lf_me(go) ? r : 0u;
+    s.endb = lf_me(go) ? s.offb + 2 - 2 * r : s.endb;
+    s.left -= r;
+    if (HAS_Q) s.qleft -= lf_me(s.hq) ? 0u : r;
+    const lane_flag fin = lf_of(!(s.left > 0 && ((int32_t)s.endb > (int32_t)s.lob ||
+                                                 (!lf_me(s.in_prev) && (int32_t)s.offb2 >= (int32_t)s.lob2))));
+    s.final = lf_and_not(s.final, go) | (go & fin);
+    s.walk = lf_and_not(s.walk | resume | go, s.done);
+}
+
+// Set a lane up for entry j of its epoch's array (see sw_setup); the first service call starts its run.
+// Returns whether the position is searched at all.
+template <bool HAS_Q, class W>
+MI355_HD bool swl_setup(SwLean<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1, uint32_t prel,
+                        uint32_t nrel, uint32_t org, uint32_t bias, uint32_t checks, uint32_t checks_q) {
+    s.prel = prel;
+    s.low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
+    s.bm1 = 0;
+    s.bestd = 0;
+    s.mq = 0;
+    s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
+    s.in_prev = lf_of(false);
+    s.final = lf_of(false);
+    s.done = lf_of(false);
+    s.walk = lf_of(false);
+    s.a = org;
+    s.rv = 0;
+    s.c = 0;
+    s.nx = 0;
+    s.left = checks;
+    s.qleft = checks_q;
+    s.lob = 2 * (SW_OWN + own_b0) + 8;
+    s.offb = 2 * (SW_OWN + j - 1) + 8;
+    s.endb = s.offb + 2;  // (no run yet)
+    s.offb2 = 2 * (pb1 - 1) + 8;
+    s.lob2 = 2 * pb0 + 8;
+    s.bb = bias;
+    s.lowa = s.low;
+    const bool search = prel + 2 < nrel && checks > 0;  // else no hash byte: never searched (lz77.rs:294-301)
+    const uint32_t left = nrel - prel;
+    s.maxlen = search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u;
+    w.load128(prel, s.p16);
+    s.probe = s.p16[0] & 0xffffu;
+    return search;
+}
+
+template <bool HAS_Q>
+MI355_HD void swl_result(const SwLean<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
+    const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
+    *m = r;
+    *mq = (HAS_Q && lf_me(s.hq)) ? s.mq : r;
 }
 
 // ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------

@@ -81,7 +81,7 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
-    if (g_multi == 4) {
+    if (g_multi == 4 || g_multi == 5) {
         // the k_sort + k_match2 formulation: epochs sorted by (hash, position), lanes walk runs of the
         // sorted arrays (stages.h SortedLane); step / service alternate as on the GPU
         const uint32_t W = WINDOW_SIZE;
@@ -146,7 +146,27 @@ void stage_match(Sim& s) {
                     }
                     sw_result(ln, &m, &mq);
                 };
-                if (hasq) {
+                auto run5 = [&](auto& ln) {  // the predicated form k_match2 runs: block of steps, one service
+                    const bool search = swl_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
+                    ln.done = lf_of(!search);
+                    swl_service(ln, win, 0u, lf_of(false), lf_of(search));
+                    uint32_t guard = 0;
+                    while (lf_me(ln.walk)) {
+                        swl_steps_ref(ln, win, 3 + (guard % 4) * 3);
+                        swl_service(ln, win, 0u, lf_not(ln.walk), lf_of(false));
+                        if (++guard > 100000) break;
+                    }
+                    swl_result(ln, &m, &mq);
+                };
+                if (g_multi == 5) {
+                    if (hasq) {
+                        SwLean<true> ln;
+                        run5(ln);
+                    } else {
+                        SwLean<false> ln;
+                        run5(ln);
+                    }
+                } else if (hasq) {
                     SortedLane<true> ln;
                     run(ln);
                 } else {
