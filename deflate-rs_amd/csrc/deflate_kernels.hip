@@ -465,34 +465,64 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* r
     return add + x - v;
 }
 
-// lanes of the wave that hold the same NB-bit digit as this lane (among `valid` lanes)
+// lanes of the wave that hold the same NB-bit digit as this lane (among `valid` lanes), as two 32-bit
+// halves.  Per bit: the lanes with the bit set (one compare), and "agrees with me" = not (set XOR mine)
+// folded into the running mask -- four vector instructions.
 template <int NB>
-__device__ __forceinline__ uint64_t wave_match(uint32_t d, bool valid) {
-    uint64_t peers = __ballot(valid);
+__device__ __forceinline__ void wave_match(uint32_t d, bool valid, uint32_t* plo, uint32_t* phi) {
+    const uint64_t all = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t lo = (uint32_t)all, hi = (uint32_t)(all >> 32);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-        const bool bit = (d >> b) & 1;
-        const uint64_t bal = __ballot(valid && bit);
-        peers &= bit ? bal : ~bal;
+        const int32_t mine = __builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);  // 0 or -1
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(mine != 0);
+        lo &= ~((uint32_t)bal ^ (uint32_t)mine);
+        hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)mine);
     }
-    return peers;
+    *plo = lo;
+    *phi = hi;
 }
 
+#ifdef MI355_MATCH_STATS
+#define KS_T(i)                                                                        \
+    if (threadIdx.x == 0) {                                                            \
+        unsigned long long t_ = __builtin_readcyclecounter();                          \
+        atomicAdd(&g_mstats[i], t_ - ks_t);                                            \
+        ks_t = t_;                                                                     \
+    }
+#else
+#define KS_T(i)
+#endif
 // one stable counting-sort pass of the workgroup: key i (i < J) has digit dig(i) < 2^NB and payload
 // pay(i); put(dest, payload) stores it at its rank
 template <int NB, class Dig, class Pay, class Put>
-__device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/, uint32_t* red, Dig dig, Pay pay, Put put) {
+__device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/, uint32_t* red, Dig dig, Pay pay, Put put,
+                                          unsigned long long& ks_t, int stat0) {
     constexpr uint32_t ND = 1u << NB;
+    constexpr int NBAT = SORT_CHUNK / 64;  // batches per wave
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* mine = cnt + wv * 256;
     for (uint32_t k = lane; k < 256; k += 64) mine[k] = 0;
     wave_lds_fence();
     const uint32_t cb = wv * SORT_CHUNK;
-    for (uint32_t b = 0; b < SORT_CHUNK; b += 64) {
-        const uint32_t i = cb + b + lane;
-        if (i < J) atomicAdd(&mine[dig(i)], 1u);
+    // the digits of the wave's keys stay in registers (four per register) between the count and the scatter:
+    // the second pass reads them through an indirection it then does not have to repeat
+    uint32_t dc[NBAT / 4];
+#pragma unroll
+    for (int b = 0; b < NBAT; b++) {
+        const uint32_t i = cb + 64 * b + lane;
+        uint32_t d = 0;
+        if (i < J) {
+            d = dig(i);
+            atomicAdd(&mine[d], 1u);
+        }
+        if ((b & 3) == 0)
+            dc[b >> 2] = d;
+        else
+            dc[b >> 2] |= d << (8 * (b & 3));
     }
     __syncthreads();
+    KS_T(stat0)
     // offsets in (digit, wave) order: thread t takes digit t / 4, waves 4 * (t % 4) ..+3
     uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
     const uint32_t d4 = tid >> 2, w4 = (tid & 3) * 4;
@@ -512,27 +542,33 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
         }
     }
     __syncthreads();
-    for (uint32_t b = 0; b < SORT_CHUNK; b += 64) {
-        const uint32_t i = cb + b + lane;
+    KS_T(stat0 + 1)
+#pragma unroll
+    for (int b = 0; b < NBAT; b++) {
+        const uint32_t i = cb + 64 * b + lane;
         const bool valid = i < J;
-        const uint32_t d = valid ? dig(i) : 0u;
-        const uint64_t peers = wave_match<NB>(d, valid);
-        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t d = (dc[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const uint32_t py = valid ? pay(i) : 0u;
+        uint32_t plo, phi;
+        wave_match<NB>(d, valid, &plo, &phi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t total = (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi);
         uint32_t at = 0;
         if (valid) at = mine[d];
         wave_lds_fence();  // every lane has read its offset before the last lane of each digit moves it on
         if (valid) {
-            put(at + below, pay(i));
-            if (((peers >> lane) >> 1) == 0) mine[d] = at + (uint32_t)__popcll(peers);
+            put(at + below, py);
+            if (below + 1 == total) mine[d] = at + total;
         }
         wave_lds_fence();
     }
     __syncthreads();
+    KS_T(stat0 + 2)
 }
 
 __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
                                                uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0) {
-    __shared__ uint16_t sH[WINDOW_SIZE];
+    __shared__ __attribute__((aligned(16))) uint16_t sH[WINDOW_SIZE];  // hashes; the sorted array at the end
     __shared__ __attribute__((aligned(16))) uint32_t sBuf[WINDOW_SIZE / 2];  // histogram (u16 pairs), then pass-1 output (u16)
     __shared__ uint32_t sCnt[16 * 256];
     __shared__ uint32_t sRed[16];
@@ -540,27 +576,37 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     const uint32_t e = e0 + blockIdx.x;
     const uint64_t E = (uint64_t)e * WINDOW_SIZE;
     const uint32_t J = epoch_active(n, E);
+    unsigned long long ks_t = __builtin_readcyclecounter();
+    (void)ks_t;
     for (uint32_t k = tid; k < WINDOW_SIZE / 2; k += 1024) sBuf[k] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < J; i += 1024) {
-        const uint64_t p = E + i;
-        uint32_t a, b, c;
-        if (n >= 4) {
-            const uint32_t v = load_u32_clamped(in, p, n);
-            a = v & 0xff;
-            b = (v >> 8) & 0xff;
-            c = (v >> 16) & 0xff;
-        } else {
-            a = in[p];
-            b = in[p + 1];
-            c = in[p + 2];
+    // hashes (chained_hash_table.rs:55-62) and their histogram; eight positions per thread and round so
+    // that the loads of a round are in flight together
+    for (uint32_t i0 = 0; i0 < J; i0 += 8 * 1024) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = i0 + 1024 * k + tid;
+            const uint64_t p = E + (i < J ? i : 0u);
+            if (n >= 4) {
+                v[k] = load_u32_clamped(in, p, n);
+            } else {
+                v[k] = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);  // (J > 0: n == 3, p == 0)
+            }
         }
-        const uint32_t ab = rewarm_ab(ov, p, a, b);
-        const uint32_t h = hash3(ab & 0xff, ab >> 8, c);
-        sH[i] = (uint16_t)h;
-        atomicAdd(&sBuf[h >> 1], (h & 1) ? 0x10000u : 1u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = i0 + 1024 * k + tid;
+            if (i < J) {
+                const uint32_t ab = rewarm_ab(ov, E + i, v[k] & 0xff, (v[k] >> 8) & 0xff);
+                const uint32_t h = hash3(ab & 0xff, ab >> 8, (v[k] >> 16) & 0xff);
+                sH[i] = (uint16_t)h;
+                atomicAdd(&sBuf[h >> 1], (h & 1) ? 0x10000u : 1u);
+            }
+        }
     }
     __syncthreads();
+    KS_T(0)
     {   // bucket starts: thread t owns bins 32 t .. 32 t + 31
         uint32_t wds[16], sum = 0;
         const uint4* src = reinterpret_cast<const uint4*>(sBuf + tid * 16);
@@ -590,14 +636,19 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         if (tid == 1023) Bg[(size_t)e * BSTRIDE + WINDOW_SIZE] = (uint16_t)J;
     }
     __syncthreads();
+    KS_T(1)
     uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
     sort_pass<8>(
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
-        [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; });
-    uint16_t* out = Sg + (size_t)e * WINDOW_SIZE;
+        [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2);
+    // (the second pass has read every hash it needs -- the digits sit in registers -- before its first store,
+    // a workgroup barrier lies in between: the sorted array can take the place of the hashes)
     sort_pass<7>(
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
-        [&](uint32_t at, uint32_t v) { out[at] = (uint16_t)v; });
+        [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
+    uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
+    const uint4* fin = reinterpret_cast<const uint4*>(sH);
+    for (uint32_t k = tid; k < (J + 7) / 8; k += 1024) out[k] = fin[k];
 }
 
 // ---------------------------------------------------------------------------------------------
