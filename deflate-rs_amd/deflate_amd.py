@@ -159,6 +159,9 @@ def load():
     L.mi355_deflate_stream_flush.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_finish.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_output.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t)]
+    L.mi355_deflate_stream_take_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_deflate_bound_ex.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]
+    L.mi355_deflate_bound_ex.restype = C.c_size_t
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_free.restype = None
@@ -167,12 +170,13 @@ def load():
 
 
 EXPORTED = [
-    "mi355_deflate_version", "mi355_deflate_bound", "mi355_deflate_preset", "mi355_deflate_ctx_create",
+    "mi355_deflate_version", "mi355_deflate_bound", "mi355_deflate_bound_ex", "mi355_deflate_preset", "mi355_deflate_ctx_create",
     "mi355_deflate_ctx_destroy", "mi355_deflate_last_error", "mi355_deflate_encode",
     "mi355_deflate_encode_device", "mi355_deflate_last_info", "mi355_deflate_last_blocks", "mi355_adler32_device",
     "mi355_deflate_stream_new", "mi355_deflate_stream_write", "mi355_deflate_stream_flush",
     "mi355_deflate_stream_finish",
-    "mi355_deflate_stream_output", "mi355_deflate_stream_checksum", "mi355_deflate_stream_free",
+    "mi355_deflate_stream_output", "mi355_deflate_stream_take_output", "mi355_deflate_stream_checksum",
+    "mi355_deflate_stream_free",
     "mi355_deflate_ctx_reserve", "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset",
     "mi355_deflate_encode_gzip",
     "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
@@ -365,21 +369,45 @@ class _Encoder:
             raise DeflateError(rc, "stream_new")
         self._s = h
 
+    def _drain(self):
+        """Hand what the encoder has produced to the inner writer, the way the reference does
+        (compress.rs:96-124, 280-299; writer.rs:40-47): `W.write` may accept fewer bytes than offered
+        (tests/test.rs:163-200 SmallWriter); a writer that returns None took everything."""
+        L = load()
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        while True:
+            L.mi355_deflate_stream_output(self._s, C.byref(p), C.byref(n))
+            if not n.value:
+                return
+            chunk = C.string_at(p, n.value)
+            took = self._w.write(chunk)
+            took = len(chunk) if took is None else int(took)
+            if took <= 0:
+                raise IOError("inner writer accepted no bytes (io::ErrorKind::WriteZero)")
+            k = C.c_size_t(0)
+            buf = (C.c_uint8 * took)()
+            L.mi355_deflate_stream_take_output(self._s, buf, took, C.byref(k))
+
     def write(self, buf):
         """io::Write::write (always consumes everything, like write_all)"""
         buf = bytes(buf)
         rc = load().mi355_deflate_stream_write(self._s, buf, len(buf))
         if rc != OK:
             raise DeflateError(rc, "stream_write")
+        self._drain()
         return len(buf)
 
     write_all = write
 
     def flush(self):
-        """io::Write::flush = Flush::Sync (writer.rs:134-137): sync marker, window kept"""
-        rc = load().mi355_deflate_stream_flush(self._s)
+        """io::Write::flush = Flush::Sync (writer.rs:134-137): sync marker, window kept; the inner writer
+        holds the bytes -- ending in 00 00 FF FF -- when this returns (writer.rs:570-595)"""
+        L = load()
+        rc = L.mi355_deflate_stream_flush(self._s)
         if rc != OK:
-            raise DeflateError(rc, "stream_flush")
+            raise DeflateError(rc, L.mi355_deflate_last_error(self._ctx._h).decode())
+        self._drain()
 
     def finish(self):
         """finish(self) -> W (writer.rs:103-108, 209-214)"""
@@ -387,10 +415,8 @@ class _Encoder:
         rc = L.mi355_deflate_stream_finish(self._s)
         if rc != OK:
             raise DeflateError(rc, L.mi355_deflate_last_error(self._ctx._h).decode())
-        p = C.POINTER(C.c_uint8)()
-        n = C.c_size_t(0)
-        L.mi355_deflate_stream_output(self._s, C.byref(p), C.byref(n))
-        self._w.write(C.string_at(p, n.value) if n.value else b"")
+        self._drain()
+        self._done = True
         return self._w
 
     def reset(self, writer):
@@ -402,9 +428,24 @@ class _Encoder:
         rc = L.mi355_deflate_stream_reset(self._s, C.byref(p), C.byref(n))
         if rc != OK:
             raise DeflateError(rc, L.mi355_deflate_last_error(self._ctx._h).decode())
-        self._w.write(C.string_at(p, n.value) if n.value else b"")
+        rest = C.string_at(p, n.value) if n.value else b""
+        while rest:
+            took = self._w.write(rest)
+            took = len(rest) if took is None else int(took)
+            if took <= 0:
+                raise IOError("inner writer accepted no bytes (io::ErrorKind::WriteZero)")
+            rest = rest[took:]
         old, self._w = self._w, writer
         return old
+
+    def close(self):
+        """Drop (writer.rs:139-152): an encoder that goes away unfinished finishes its stream; errors are
+        swallowed, as Drop must"""
+        if getattr(self, "_s", None) and not getattr(self, "_done", False):
+            try:
+                self.finish()
+            except Exception:
+                pass
 
     def checksum(self):
         """{Zlib,Gz}Encoder::checksum() (writer.rs:248-250, :428-430)"""
@@ -417,6 +458,7 @@ class _Encoder:
     def __del__(self):
         if getattr(self, "_s", None):
             try:
+                self.close()
                 load().mi355_deflate_stream_free(self._s)
             except Exception:
                 pass

@@ -80,20 +80,27 @@ int mi355_deflate_preset(int level, mi355_deflate_opts* out);
 
 int mi355_deflate_version(void);
 
-/* Upper bound of the output size for in_len input bytes (all-stored worst case + framing). */
+/* Upper bound of the output size for in_len input bytes: every block is at most its stored form
+ * (src/huffman_lengths.rs:269-286 picks the cheapest, src/stored_block.rs:13-40), plus the framing of any
+ * wrapper with the blank gzip header.  mi355_deflate_bound_ex is the exact requirement of the encode
+ * entry points for a given wrapper (0 raw, 1 zlib, 2 gzip with hdr_len header bytes) and number of sync
+ * flush points (each can add a block header and the marker 00 00 FF FF, src/compress.rs:256-261); a
+ * buffer of mi355_deflate_bound(in_len) bytes is always enough for a one-shot call. */
 size_t mi355_deflate_bound(size_t in_len);
+size_t mi355_deflate_bound_ex(size_t in_len, int wrapper, size_t hdr_len, size_t n_flush);
 
 /* A context owns one HIP device, its workspace and timing events.  Not thread safe; use one
  * context per thread (the reference's encoders are likewise single-owner: DeflateState,
- * src/deflate_state.rs:66-97). */
+ * src/deflate_state.rs:66-97).  Where an entry point accepts ctx == NULL it works on a process-wide
+ * default context on device 0 and holds that context's lock for the whole call, so NULL-context calls
+ * from several threads are safe (and serialised). */
 typedef struct mi355_deflate_ctx mi355_deflate_ctx;
 int mi355_deflate_ctx_create(int device, mi355_deflate_ctx** out);
 void mi355_deflate_ctx_destroy(mi355_deflate_ctx* ctx);
 const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
- * in, host buffer out.  ctx may be NULL (a process-wide default context on device 0 is used,
- * mutex guarded). */
+ * in, host buffer out.  ctx may be NULL (the default context, see above). */
 int mi355_deflate_encode(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
                          uint8_t* out, size_t out_cap, size_t* out_len);
 
@@ -105,8 +112,10 @@ int mi355_deflate_ctx_reserve(mi355_deflate_ctx* ctx, size_t in_len, int host_ap
 
 /* Same computation with input and output resident in device memory (no PCIe in the path):
  * compress_data_dynamic + compress_until_done(.., Flush::Finish) (src/lib.rs:110-122,
- * src/writer.rs:15-58) over d_in[0..in_len).  d_out needs mi355_deflate_bound(in_len) bytes
- * (+4 slack, rounded up to 4).  `hip_stream` is a hipStream_t (NULL = default stream); the
+ * src/writer.rs:15-58) over d_in[0..in_len).  d_out must be 4-byte aligned and hold
+ * mi355_deflate_bound(in_len) bytes (exactly: mi355_deflate_bound_ex(in_len, opts->wrapper, 10, 0); a
+ * smaller buffer is refused with MI355_E_OUT_TOO_SMALL and the size in *out_len).  `hip_stream` is a
+ * hipStream_t (NULL = the context's own stream); the
  * call returns after the stream has drained, with *out_len set.  Always raw deflate unless
  * opts->wrapper == 1, in which case the 2-byte header and 4-byte trailer are written too. */
 int mi355_deflate_encode_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, const mi355_deflate_opts* opts,
@@ -202,18 +211,24 @@ int mi355_crc32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, 
  * src/checksum.rs:33-57), computed on the GPU. */
 int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, uint32_t* adler, void* hip_stream);
 
-/* Streaming encoder mirroring write::{DeflateEncoder, ZlibEncoder}<W> (src/writer.rs:89-290):
- *   _new      = ::new(W, options)                    :93-99 / :189-199
- *   _write    = io::Write::write_all                 :124-127 / :254-267
- *   _finish   = finish(self) -> W                    :103-108 / :209-214
- *   _output   = the bytes W = Vec<u8> would hold
- *   _checksum = ZlibEncoder::checksum()              :248-250
- * Without flush() the output is independent of how the input is split across writes (the reference
- * guarantees the same: src/lz77.rs:627, test src/lib.rs:408-433), so writes and flush points are
- * gathered and encoded on the GPU at finish().  One _write call stands for one write_all call
- * (n == 0: no call at all); the size of the first write after a flush is remembered, because the
- * reference's hash re-warm at a flush point inside the first window depends on it
- * (src/lz77.rs:601-638).  */
+/* Streaming encoder mirroring write::{DeflateEncoder, ZlibEncoder, gzip::GzEncoder}<W> (src/writer.rs:89-467):
+ *   _new         = ::new(W, options)                    :93-99 / :189-199
+ *   _write       = io::Write::write_all                 :124-127 / :254-267
+ *   _flush       = io::Write::flush (Flush::Sync)       :134-137 / :274-277
+ *   _finish      = finish(self) -> W                    :103-108 / :209-214
+ *   _output      = the bytes produced and not yet taken (what the inner writer W is owed)
+ *   _take_output = hand over up to `cap` of them: the shim's loop over W::write, which may accept fewer
+ *                  bytes than offered (src/compress.rs:96-124, 280-299; tests/test.rs:163-200 issue_47)
+ *   _checksum    = {Zlib,Gz}Encoder::checksum()         :248-250 / :428-430
+ * write() only gathers (the reference likewise does nothing until its 64 KiB + 258 buffer is full,
+ * src/lz77.rs:627, and its output does not depend on how the input is split: src/lib.rs:408-433); the GPU
+ * encodes at flush() and finish(), and the bytes of a flush -- ending in 00 00 FF FF, as
+ * src/writer.rs:570-595 asserts -- are available when flush() returns.  Between flushes the handle keeps
+ * the bytes since the last flush plus the 32 KiB window before it (the whole stream while the flushed part
+ * is shorter than three windows).  One _write call stands for one write_all call (n == 0: no call at all);
+ * the size of the first write after a flush is remembered, because the reference's hash re-warm at a
+ * flush point inside the first window depends on it (src/lz77.rs:601-638).  The shim's Drop calls _finish
+ * and drains the output like the reference's (src/writer.rs:139-152). */
 typedef struct mi355_deflate_stream mi355_deflate_stream;
 int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* opts, mi355_deflate_stream** out);
 int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);
@@ -227,10 +242,11 @@ int mi355_deflate_stream_finish(mi355_deflate_stream* s);
  * write; _checksum of such a stream is GzEncoder::checksum() (:428-430), the CRC-32. */
 int mi355_deflate_stream_gzip_header(mi355_deflate_stream* s, const uint8_t* hdr, size_t hdr_len);
 /* reset(&mut self, W) -> io::Result<W> (src/writer.rs:110-117, 216-223, 383-402): finishes the stream,
- * hands its bytes out (valid until the next reset / free) and starts a new one with the same options
+ * hands its untaken bytes out (valid until the next reset / free) and starts a new one with the same options
  * (gzip: with the blank header again, as GzEncoder::reset does). */
 int mi355_deflate_stream_reset(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
 int mi355_deflate_stream_output(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
+int mi355_deflate_stream_take_output(mi355_deflate_stream* s, uint8_t* dst, size_t cap, size_t* n);
 int mi355_deflate_stream_checksum(mi355_deflate_stream* s, uint32_t* adler);
 void mi355_deflate_stream_free(mi355_deflate_stream* s);
 

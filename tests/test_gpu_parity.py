@@ -442,6 +442,135 @@ def test_flush_with_window_retention(da, ctx, level):
     assert len(one) < two * 0.7
 
 
+# writer.rs:570-595 writer_sync: right after flush() the inner writer already holds the stream up to and
+# including the sync marker 00 00 FF FF
+def test_writer_sync_bytes_are_delivered_at_flush(da, ctx):
+    import io
+    data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
+    split = len(data) // 2
+    for cls, wrapper in ((da.DeflateEncoder, 0), (da.ZlibEncoder, 1), (da.GzEncoder, 2)):
+        sink = io.BytesIO()
+        enc = cls(sink, da.Compression.Default, ctx)
+        ref = ob.Stream(ob.preset(ob.DEFAULT, wrapper))
+        if wrapper == 2:
+            ref.gzip_header(da.BLANK_GZIP_HEADER)  # GzEncoder::new = GzBuilder::new() (writer.rs:340-342)
+        enc.write_all(data[:split])
+        ref.write_all(data[:split])
+        enc.flush()
+        ref.flush()
+        held = sink.getvalue()
+        assert held[-4:] == b"\x00\x00\xff\xff"
+        assert held == ref.output()  # the reference's Vec holds the same bytes at this point
+        enc.write_all(data[split:])
+        ref.write_all(data[split:])
+        got = enc.finish().getvalue()
+        assert got == ref.finish()
+        body = got if wrapper == 0 else (got[2:-4] if wrapper == 1 else got[10:-8])
+        assert inflate_raw(body) == data
+
+
+# tests/test.rs:163-200 issue_47: a sink that takes at most two bytes per write() call
+class SmallWriter:
+    def __init__(self, small):
+        self.buf = bytearray()
+        self.small = small
+        self.calls = 0
+
+    def write(self, b):
+        k = min(len(b), self.small)
+        self.buf += b[:k]
+        self.calls += 1
+        return k
+
+
+def test_issue_47_short_write_sink(da, ctx):
+    w = SmallWriter(2)
+    enc = da.ZlibEncoder(w, da.Compression.Fast, ctx)
+    enc.flush()  # the reference's test: a flush on a fresh encoder into the small writer must not hang or fail
+    ref = ob.Stream(ob.preset(ob.FAST, 1))
+    ref.flush()
+    assert bytes(w.buf) == ref.output()
+    data = datagen.text_like(50000, 7)
+    enc.write_all(data)
+    ref.write_all(data)
+    enc.flush()
+    ref.flush()
+    assert bytes(w.buf) == ref.output() and w.calls >= len(w.buf) // 2
+    enc.finish()
+    assert bytes(w.buf) == ref.finish()
+
+
+# writer.rs:139-152 Drop: an encoder that goes away unfinished finishes its stream into the writer
+def test_drop_finishes_the_stream(da, ctx):
+    import io
+    data = datagen.text_like(30000, 3)
+    sink = io.BytesIO()
+    enc = da.ZlibEncoder(sink, da.Compression.Default, ctx)
+    enc.write_all(data)
+    del enc
+    assert zlib.decompress(sink.getvalue()) == data
+    assert sink.getvalue() == ob.encode(data, level=ob.DEFAULT, wrapper=1)
+
+
+# Per-message sync flush: hundreds of small incompressible writes, each followed by a flush -- every
+# segment costs a block header and a marker on top of its bytes (the output bound has to count them).
+def test_many_small_flushed_writes(da, ctx):
+    import io
+    for count, size, kind in ((50, 100, "rng"), (1000, 30, "rng"), (400, 300, "text")):
+        for cls, wrapper in ((da.DeflateEncoder, 0), (da.ZlibEncoder, 1)):
+            enc = cls(io.BytesIO(), da.Compression.Default, ctx)
+            ref = ob.Stream(ob.preset(ob.DEFAULT, wrapper))
+            whole = b""
+            for i in range(count):
+                piece = datagen.rng_bytes(size, i + 1) if kind == "rng" else datagen.text_like(size, i + 1)
+                whole += piece
+                enc.write_all(piece)
+                ref.write_all(piece)
+                enc.flush()
+                ref.flush()
+            got = enc.finish().getvalue()
+            assert got == ref.finish()
+            assert (zlib.decompress(got) if wrapper else inflate_raw(got)) == whole
+
+
+# A long stream with flushes: once the flushed part has passed three windows the handle keeps only the
+# 32 KiB window before the last flush point and encodes every new segment against it.
+@pytest.mark.parametrize("level", ["default", "fast", "best"])
+def test_long_stream_keeps_only_its_window(da, ctx, level):
+    import io
+    import random
+    c, l, m = LV[level]
+    rnd = random.Random(11)
+    data = datagen.text_like(900_000, 21) + datagen.mixed(300_000, 22) + (datagen.rng_bytes(257, 23) * 800)
+    for wrapper, cls in ((0, da.DeflateEncoder), (1, da.ZlibEncoder), (2, da.GzEncoder)):
+        enc = cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+        ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+        if wrapper == 2:
+            ref.gzip_header(da.BLANK_GZIP_HEADER)
+        pos = 0
+        mid = None
+        while pos < len(data):
+            step = rnd.choice([3, 700, 20_000, 33_000, 70_000, 150_000])
+            if len(data) - (pos + step) == 1:
+                step += 1
+            piece = data[pos:pos + step]
+            # several write calls per segment, never a 1-byte one
+            half = len(piece) // 2
+            for part in ((piece[:half], piece[half:]) if half >= 2 and len(piece) - half >= 2 else (piece,)):
+                enc.write_all(part)
+                ref.write_all(part)
+            pos += len(piece)
+            if pos < len(data) or rnd.random() < 0.5:
+                enc.flush()
+                ref.flush()
+            if mid is None and pos > 600_000 and wrapper:
+                mid = (enc.checksum(), ref.checksum())
+        got = enc.finish().getvalue()
+        assert got == ref.finish()
+        if mid:
+            assert mid[0] == mid[1]
+
+
 def test_flush_patterns_that_are_refused(da, ctx):
     import io
     enc = da.DeflateEncoder(io.BytesIO(), da.Compression.Default, ctx)
