@@ -121,7 +121,13 @@ __global__ __launch_bounds__(256) void k_links_a(const uint8_t* __restrict__ in,
     bool active = p + 2 < n;
     uint32_t v = load_u32_clamped(in, p < n ? p : n - 1, n);
     uint32_t a = v & 0xff, b1 = (v >> 8) & 0xff, c = (v >> 16) & 0xff;
-    const uint32_t ab = rewarm_ab(ov, p, a, b1);
+    uint32_t ab;
+    if (ov.ns | ov.nh) {  // write patterns around a sync flush that leave positions out or file them a byte late
+        ab = skewed_ab(ov, p, (p > 0 && p <= n) ? (uint32_t)in[p - 1] : 0u, a, b1);
+        active = active && !hash_hole(ov, p);
+    } else {
+        ab = rewarm_ab(ov, p, a, b1);
+    }
     uint32_t h = active ? hash3(ab & 0xff, ab >> 8, c) : 0;
     uint64_t peers = __ballot(active);
 #pragma unroll

@@ -77,21 +77,33 @@ struct HashOverride {
     uint32_t on;
     uint32_t m;
     const uint32_t* pts;
+    // Two more effects of write calls around a sync flush (streaming API only; lz77.rs:601-614).  The
+    // first write after a flush point F > 2 re-adds the positions F-2 and F-1 with its first two bytes; a
+    // write of ONE byte re-adds only F-2: F-1 is never filed (`hol`, ascending), and the rolling hash is a
+    // byte behind when F and F+1 are filed -- under (d[F-1], d[F], d[F+2]) and (d[F], d[F+2], d[F+3])
+    // (`skw` = those F, ascending).  After a flush at F <= 2 nothing is re-added: the positions before F
+    // are holes as well, and F is a re-warm point (`pts`).
+    uint32_t ns;
+    const uint32_t* skw;
+    uint32_t nh;
+    const uint32_t* hol;
 };
 
-MI355_HD bool rewarm_listed(const HashOverride& ov, uint32_t p) {
-    uint32_t lo = 0, hi = ov.m;
+MI355_HD bool list_has(const uint32_t* v, uint32_t n, uint32_t p) {
+    uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        uint32_t v = ov.pts[mid];
-        if (v == p) return true;
-        if (v < p)
+        uint32_t x = v[mid];
+        if (x == p) return true;
+        if (x < p)
             lo = mid + 1;
         else
             hi = mid;
     }
     return false;
 }
+MI355_HD bool rewarm_listed(const HashOverride& ov, uint32_t p) { return list_has(ov.pts, ov.m, p); }
+MI355_HD bool hash_hole(const HashOverride& ov, uint64_t p) { return ov.nh && p <= 0xFFFFFFFFull && list_has(ov.hol, ov.nh, (uint32_t)p); }
 
 // the first two bytes of position p's 3-byte hash input, replaced where a re-warm applies; returned
 // packed (a | b << 8) -- by value, so that nothing has to live in memory
@@ -108,10 +120,23 @@ MI355_HD uint32_t rewarm_ab(const HashOverride& ov, uint64_t p, uint32_t a, uint
     }
     return a | (b << 8);
 }
+// the same with the one-byte-write skew in front of it (a re-warm at the same point replaces the rolling
+// hash and wins); prev = d[p-1]
+MI355_HD uint32_t skewed_ab(const HashOverride& ov, uint64_t p, uint32_t prev, uint32_t a, uint32_t b) {
+    if (ov.ns && p <= 0xFFFFFFFFull) {
+        if (list_has(ov.skw, ov.ns, (uint32_t)p)) {
+            b = a;
+            a = prev;
+        } else if (p > 0 && list_has(ov.skw, ov.ns, (uint32_t)p - 1)) {
+            a = prev;
+        }
+    }
+    return rewarm_ab(ov, p, a, b);
+}
 
 template <class Bytes>
 MI355_HD uint32_t position_hash(const Bytes& by, uint64_t p, const HashOverride& ov) {
-    const uint32_t ab = rewarm_ab(ov, p, by(p), by(p + 1));
+    const uint32_t ab = skewed_ab(ov, p, p ? by(p - 1) : 0u, by(p), by(p + 1));
     return hash3(ab & 0xff, ab >> 8, by(p + 2));
 }
 

@@ -51,7 +51,7 @@ struct Sim {
     std::vector<uint32_t> tokens;
     std::vector<uint64_t> tok_pos;
     int hier_mismatch = 0;
-    HashOverride ov = {0, 0, 0, 0, 0, nullptr};  // what stage_links was given (mode 4 sorts by the same hashes)
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr};  // what stage_links was given (mode 4 sorts by the same hashes)
 };
 
 void stage_links(Sim& s, const HashOverride& ov) {
@@ -393,7 +393,7 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
     if (s.cfg.mode == MODE_LAZY && s.cfg.lazy_lt < 3) return -4;  // unsupported
     *flags = 0;
 
-    HashOverride ov = {0, 0, 0, 0, 0, nullptr};
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
     for (int pass = 0; pass < 2; pass++) {
         if (s.cfg.mode != MODE_RLE && checks > 0) stage_links(s, ov);
         stage_match(s);
@@ -594,7 +594,7 @@ int hostsim_match_table(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t
     s.cfg.lazy_lt = 32;
     s.cfg.mode = MODE_LAZY;
     s.cfg.use_quarter = 0;
-    HashOverride ov = {0, 0, 0, 0, 0, nullptr};
+    HashOverride ov = {0, 0, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
     stage_links(s, ov);
     stage_match(s);
     for (uint64_t i = 0; i < n; i++) m_out[i] = s.M[i];

@@ -571,16 +571,56 @@ def test_long_stream_keeps_only_its_window(da, ctx, level):
             assert mid[0] == mid[1]
 
 
-def test_flush_patterns_that_are_refused(da, ctx):
+# tests/test.rs:113-123 issue_26 (write, flush, one-byte write, write, drop) and its relatives: a one-byte
+# write right after a flush files one position less and two a byte late (lz77.rs:605-614), a flush after
+# one or two bytes leaves the first positions out of the chains and re-warms the hash (lz77.rs:606,628-638).
+# Periodic data makes every misfiled position show up as a different distance.
+def test_issue_26_and_the_write_patterns_around_a_flush(da, ctx):
     import io
-    enc = da.DeflateEncoder(io.BytesIO(), da.Compression.Default, ctx)
-    enc.write_all(b"x" * 1000)
-    enc.flush()
-    enc.write_all(b"y")  # 1-byte write right after a flush: lz77.rs:605-614 leaves one position unhashed
-    enc.write_all(b"z" * 100)
-    with pytest.raises(da.DeflateError) as e:
-        enc.finish()
-    assert e.value.code == da.E_UNSUPPORTED
+    per = datagen.rng_bytes(300, 3) * 500
+    txt = datagen.text_like(400_000, 31)
+    scripts = [
+        [b"\0", "F", b"\0", b"\0\0"],                                     # issue_26 itself
+        [b"x" * 1000, "F", b"y", b"z" * 100],
+        [per[:5000], "F", per[5000:5001], per[5001:90000]],
+        [per[:5000], "F", per[5000:5001], "F", per[5001:5002], per[5002:90000]],
+        [per[:1], "F", per[1:90000]],
+        [per[:2], "F", per[2:90000]],
+        [per[:1], "F", per[1:2], "F", per[2:90000]],
+        [per[:2], "F", per[2:3], per[3:90000]],
+        [per[:40000], "F", per[40000:40001], per[40001:40900], "F", per[40900:120000]],
+        [txt[:250_000], "F", txt[250_000:250_001], per[:60000], "F", txt[250_001:250_002], txt[250_002:]],  # past the first windows
+        [txt[:150_000], "F", txt[150_000:200_000], "F", per[:1], per[1:50000], "F", per[50000:50001], "F", per[50001:120000]],
+        [per[:30000], "F", per[30000:30001], "F", per[30001:30002], "F", per[30002:30003], per[30003:30004], "F", per[30004:100000]],
+        [per[:30000], "F", per[30000:30001], per[30001:30002], "F", per[30002:30003], "F", per[30003:100000]],
+    ]
+    refused = 0
+    for lv in ("default", "fast", "best"):
+        c, l, m = LV[lv]
+        for script in scripts:
+            for cls, wrapper in ((da.DeflateEncoder, 0), (da.ZlibEncoder, 1)):
+                enc = cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+                ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+                whole = b""
+                try:
+                    for op in script:
+                        if op == "F":
+                            enc.flush()
+                            ref.flush()
+                        else:
+                            enc.write_all(op)
+                            ref.write_all(op)
+                            whole += op
+                except da.DeflateError as e:
+                    # the one pattern that is refused instead of reproduced: two flushes one or two bytes apart
+                    assert e.code == da.E_UNSUPPORTED
+                    enc._done = True
+                    refused += 1
+                    continue
+                got = enc.finish().getvalue()
+                assert got == ref.finish(), (lv, [x if x == "F" else len(x) for x in script], wrapper)
+                assert (zlib.decompress(got) if wrapper else inflate_raw(got)) == whole
+    assert refused == 3 * 2 * 4  # the four scripts with such a pair of flushes, at every level and wrapper
 
 
 # ---- gzip wrapper, CRC-32 on the GPU (feature "gzip": lib.rs:242-286, writer.rs:293-467) ----
