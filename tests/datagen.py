@@ -147,3 +147,64 @@ def silesia_like(seed=0x53494C45, scale=1.0):
              rng_bytes(mb(7.3), int(rng.integers(1 << 30))),
              text_like(mb(5.3), int(rng.integers(1 << 30)))]
     return b"".join(parts)
+
+
+_WEB = None
+
+
+def _web_table():
+    """webtext(): vocabulary words, HTML-ish template pieces and separators as one flat byte array"""
+    global _WEB
+    if _WEB is None:
+        words, _ = _vocab()
+        tags = ["<div class=\"post\">", "</div>", "<p>", "</p>", "<a href=\"http://www.", ".com/", ".html\">", "</a>",
+                "<span>", "</span>", "<li>", "</li>", "<ul>", "</ul>", "<br/>", "<h2>", "</h2>", "&nbsp;", "&amp;",
+                "<img src=\"/img/", ".png\" alt=\"", "\"/>", "<td>", "</td>", "<tr>", "</tr>", "\n", "\n\n"]
+        seps = [" ", " ", " ", " ", " ", ", ", ". ", "? ", " - ", " ", ""]  # (the empty one follows a tag)
+        rows = [w.encode() for w in words] + [t.encode() for t in tags] + [x.encode() for x in seps]
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+        flat = np.frombuffer(b"".join(rows), dtype=np.uint8)
+        ranks = np.arange(1, len(words) + 1, dtype=np.float64)
+        p = ranks ** -1.05
+        p /= p.sum()
+        _WEB = (flat, starts, lens, len(words), len(tags), len(seps), np.cumsum(p))
+    return _WEB
+
+
+WEB_SEGMENT = 1 << 20
+
+
+def webtext_segment(index, seed=0x57454254):
+    """One 1 MiB segment of the config-5 workload: HTML-ish templates around Zipf(1.05)
+    words, generated from seed ^ index alone -- any rank regenerates exactly its own part of the 8 GiB
+    input (plus the halo it needs) without anybody shipping the whole."""
+    flat, starts, lens, nw, nt, ns, cdf = _web_table()
+    rng = np.random.default_rng((seed ^ index) & 0xFFFFFFFFFFFF)
+    k = 190_000  # tokens: about 1.1 MiB (mean token + separator is 6.1 bytes); topped up below if short
+    out = []
+    have = 0
+    while have < WEB_SEGMENT:
+        w = np.searchsorted(cdf, rng.random(k), side="right").clip(0, nw - 1)
+        tg = rng.random(k) < 0.12
+        ti = rng.integers(0, nt, size=k) + nw
+        sp = rng.integers(0, ns - 1, size=k) + nw + nt
+        rows = np.empty(2 * k, dtype=np.int64)
+        rows[0::2] = np.where(tg, ti, w)
+        rows[1::2] = np.where(tg, nw + nt + ns - 1, sp)
+        ln = lens[rows]
+        total = int(ln.sum())
+        src0 = np.repeat(starts[rows] - (np.cumsum(ln) - ln), ln)
+        chunk = flat[src0 + np.arange(total)]
+        out.append(chunk)
+        have += total
+    return (np.concatenate(out) if len(out) > 1 else out[0])[:WEB_SEGMENT]
+
+
+def webtext(n, seed=0x57454254, start=0):
+    """bytes [start, start + n) of the web-text workload"""
+    first, last = start // WEB_SEGMENT, (start + n + WEB_SEGMENT - 1) // WEB_SEGMENT
+    parts = [webtext_segment(i, seed) for i in range(first, max(last, first + 1))]
+    a = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    off = start - first * WEB_SEGMENT
+    return a[off:off + n].tobytes()

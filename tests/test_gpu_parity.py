@@ -261,6 +261,68 @@ def test_config3_full_size_properties(da, ctx):
     assert bytes(out[:k2].cpu().numpy()) == ob.encode(data[:m], level=ob.DEFAULT)
 
 
+def _big_gold(name):
+    import json
+    return json.load(open(os.path.join(HERE, "golden", "big_digests.json")))["digests"][name]
+
+
+def _encode_resident(da, ctx, data, options):
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = da.bound(len(data)) + 8
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    k = ctx.encode_device(t.data_ptr(), len(data), out.data_ptr(), cap, options)
+    return bytes(out[:k].cpu().numpy())
+
+
+# BASELINE config 3 at full size against the oracle's stream, by its committed digest
+# (tests/golden/big_digests.json, written by gen_big_digests.py and re-derived by the CPU suite)
+def test_config3_full_size_equals_the_oracle(da, ctx):
+    import hashlib
+    g = _big_gold("config3_enwik8_like_100MB_default")
+    data = datagen.text_like(100_000_000, 0x656E77696B38)
+    assert hashlib.sha256(data).hexdigest() == g["in_sha256"]
+    got = _encode_resident(da, ctx, data, da.Compression.Default)
+    assert [len(got), hashlib.sha256(got).hexdigest()] == [g["out_len"], g["out_sha256"]]
+
+
+# BASELINE config 4: the Silesia-like mix (212 100 000 bytes: text, binary records, database rows, 16-bit
+# samples, noise) at Compression::Best -- compression_options.rs:126-133, quarter budget lz77.rs:351-355 --
+# byte for byte against the oracle (digest), plus the block invariants and an inflate round trip
+def test_config4_silesia_like_best_full_size(da, ctx):
+    import hashlib
+    g = _big_gold("config4_silesia_like_best")
+    data = datagen.silesia_like(0x53494C45)
+    assert len(data) == g["in_len"] and hashlib.sha256(data).hexdigest() == g["in_sha256"]
+    got = _encode_resident(da, ctx, data, da.Compression.Best)
+    bl = ctx.blocks()
+    assert sum(b["in_bytes"] for b in bl) == len(data)
+    assert all(b["n_lz"] == 31744 for b in bl[:-1])
+    assert {b["btype"] for b in bl} == {0, 2} or {b["btype"] for b in bl} == {0, 1, 2}  # stored (noise) and dynamic
+    assert [len(got), hashlib.sha256(got).hexdigest()] == [g["out_len"], g["out_sha256"]]
+    assert zlib.crc32(inflate_raw(got)) == zlib.crc32(data)
+
+
+# BASELINE config 5 workload: the web-text input (generated per 1 MiB segment from seed ^ index),
+# its first 256 MiB sharded stream-exact over eight virtual ranks on this one GPU -- the exchanges of the
+# distributed driver, byte for byte the oracle's single stream
+def test_config5_webtext_sharded_over_8_virtual_ranks(da, ctx):
+    import hashlib
+    import shard
+    g = _big_gold("config5_webtext_256MiB_default")
+    data = datagen.webtext(256 << 20)
+    assert hashlib.sha256(data).hexdigest() == g["in_sha256"]
+    ctxs = [da.Context(0) for _ in range(8)]
+    try:
+        got = shard.encode_p1_virtual(da, ctxs, data, da.Compression.Default, compat=1)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert [len(got), hashlib.sha256(got).hexdigest()] == [g["out_len"], g["out_sha256"]]
+    one = _encode_resident(da, ctx, data, da.Compression.Default)
+    assert one == got
+
+
 # MI355_FLUSH_SYNC == fresh reference encoder: write_all(chunk); flush() (writer.rs:134-137,
 # compress.rs:256-261) -- the chunk form the multi-GPU stitch concatenates
 def test_sync_flush_chunks_and_stitch(da, ctx):

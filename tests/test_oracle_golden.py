@@ -36,3 +36,17 @@ def test_oracle_reproduces_the_digests():
 def test_deflate_late_vector_is_in_the_goldens():
     assert GOLD["streams"]["synthetic/deflate_late|best|raw"] == "73494dcb492c4955001100"
     assert GOLD["streams"]["synthetic/empty|default|raw"] == "0300"
+
+
+# the full-size BASELINE workloads (config 3, 4 and the config-5 input): the digests the GPU tests hold the
+# HIP path to are the oracle's, re-derived here
+def test_big_digests_are_the_oracles():
+    import json
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import gen_big_digests
+    gold = json.load(open(os.path.join(HERE, "golden", "big_digests.json")))["digests"]
+    seen = 0
+    for name, make, level in gen_big_digests.workloads():
+        assert gen_big_digests.digest(name, make, level) == gold[name], name
+        seen += 1
+    assert seen == 3
