@@ -6,7 +6,14 @@ the task statement; prints ONE JSON line on rank 0.
 
 Workloads (BASELINE.json configs): "enwik8" = 100 000 000 bytes of enwik8-like text, Default,
 dynamic-Huffman blocks (the configuration the metric is quoted on; default); "zeros" = 256 MiB zero
-fill through the RLE path (config 2); "random" = 64 MiB noise (stored blocks).
+fill through the RLE path (config 2); "random" = 64 MiB noise (stored blocks); "silesia" = the
+Silesia-like mix at Compression::Best (config 4); "webtext" = config 5: every rank owns 1 GiB of ONE
+N GiB web-text input (generated per 1 MiB segment, so a rank makes exactly its own part).
+
+Besides the contract's fields the line carries: value_host_api (the drop-in call on pinned host buffers,
+H2D and D2H inside the timed region), roofline.input_load (achieved HBM GB/s of the kernel that reads
+the input coalesced) and roofline.lds_bank_conflict_rate of the match compare (committed PMC file),
+cpu_baseline as the median of five runs with its all-cores and zlib companions.
 """
 import argparse
 import json
@@ -32,7 +39,59 @@ def make_input(workload, size, rank):
     if workload == "silesia":  # BASELINE config 4: twelve pieces by entropy class, Silesia's file sizes
         d = datagen.silesia_like(0x53494C45 ^ rank)
         return d if size >= len(d) else d[:size]
+    if workload == "webtext":  # BASELINE config 5: this rank's part of the one big input
+        return datagen.webtext(size, start=rank * size)
     raise SystemExit("unknown workload " + workload)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baselines(data, olvl, level_name):
+    """The oracle (C++ restatement of deflate-rs, same algorithm) on the host cores, on a bounded sample:
+    median of five single-thread runs; the same sample cut into one chunk per core and encoded by all cores
+    at once (chunk-exact form, P2: what N independent reference encoders would do); system zlib -6 as an
+    anchor that is NOT the reference."""
+    import statistics
+    import threading
+    import zlib
+    import oracle_binding as ob
+    ncpu = os.cpu_count() or 1
+    sample = data[: min(len(data), 16_000_000)]
+    times = []
+    for _ in range(5):
+        t = time.perf_counter()
+        ob.encode(sample, level=olvl)
+        times.append(time.perf_counter() - t)
+    one = len(sample) / statistics.median(times) / 1e6
+    big = data[: min(len(data), ncpu * 8_000_000)]
+    step = (len(big) + ncpu - 1) // ncpu
+    chunks = [big[i:i + step] for i in range(0, len(big), step)]
+    th = [threading.Thread(target=ob.encode, args=(c,), kwargs={"level": olvl}) for c in chunks]  # (ctypes drops the GIL)
+    t = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    allc = len(big) / (time.perf_counter() - t) / 1e6
+    t = time.perf_counter()
+    zlib.compress(sample, 6)
+    z6 = len(sample) / (time.perf_counter() - t) / 1e6
+    return {"value": round(one, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d bytes of the workload, %s, median of 5 runs of the single-threaded C++ restatement "
+                      "of deflate-rs (oracle/)" % (len(sample), level_name),
+            "runs_s": [round(x, 3) for x in times], "host_cores": ncpu, "cpu_model": cpu_model(),
+            "all_cores": {"value": round(allc, 2), "unit": "MB/s", "cores": len(chunks),
+                          "sample": "first %d bytes in %d chunks, one oracle encoder per core (chunk-exact, P2)" % (
+                              len(big), len(chunks))},
+            "zlib6_anchor": {"value": round(z6, 2), "unit": "MB/s", "cores": 1, "note": "system zlib -6, not the reference"}}
 
 
 def main():
@@ -40,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random", "silesia"])
+    ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random", "silesia", "webtext"])
     ap.add_argument("--size", type=int, default=0, help="bytes per GPU (0 = the config's size)")
     ap.add_argument("--level", default="", choices=["", "default", "best", "fast", "rle", "huffman_only"],
                     help="override the level of the workload (default: Default, rle() for zeros)")
@@ -73,7 +132,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     size = args.size or {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024,
-                         "silesia": 212_100_000}[args.workload]
+                         "silesia": 212_100_000, "webtext": 1 << 30}[args.workload]
     shard_mode = os.environ.get("MI355_SHARD_MODE", "p1") if world > 1 else "single"
     if world > 1:
         size = (size + 32767) // 32768 * 32768  # rank ranges of the one big input are 32 KiB aligned
@@ -189,17 +248,32 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * size * args.steps / elapsed / 1e6
         mm = sum(match_ms) / len(match_ms)
-        dominant = "k_rle" if lvl == "rle" else "k_match"
+        sorted_walk = lvl in ("default", "best") and os.environ.get("MI355_MATCH_PATH", "2") != "1"
+        dominant = "k_rle" if lvl == "rle" else ("k_match2" if sorted_walk else "k_match")
         # 1 B read + r B written per input byte; one launch of the dominant kernel = one rank's bytes
         algo_bytes = size + (total_out // world)
         achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0
-        traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        # HBM bytes per launch of the dominant kernel and the LDS bank-conflict rate of the match compare, from
+        # the committed PMC passes of this very command (profiles/, FETCH_SIZE doubled as the guide prescribes)
+        traffic = None
+        lds_conflict = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            if pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and lvl == "default":
-                traffic = pm["kernels"]["k_match<false>"]["hbm_bytes"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            if pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1:
+                traffic = pm["kernels"][dominant]["hbm_bytes"]
+                lds_conflict = pm["kernels"][dominant].get("lds_bank_conflict_rate")
         except Exception:
-            traffic = None
+            pass
+        # the kernel that reads the input coalesced: k_sort files every position under its hash (reads n, writes
+        # the sorted array and the bucket starts, 2 B per position each); on the unsorted path k_links_a
+        links_ms = stage_ms.get("links", 0.0) / args.steps if stage_ms else 0.0
+        in_kernel = "k_sort" if sorted_walk else "k_links_a+k_links_b"
+        in_bytes = size * 5
+        input_load = None
+        if links_ms > 0 and lvl not in ("rle", "huffman_only"):
+            input_load = {"kernel": in_kernel, "bytes": in_bytes, "ms": round(links_ms, 3),
+                          "achieved": round(in_bytes / (links_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                          "frac": round(in_bytes / (links_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         res = {
             "metric": "MB/s raw input encoded (%s) + compressed size vs ref" % level_name,
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,20 +290,35 @@ def main():
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes},
+                         "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes,
+                         "input_load": input_load, "lds_bank_conflict_rate": lds_conflict},
         }
+        if world == 1:
+            # the drop-in call itself, deflate_bytes(&[u8]) -> Vec<u8> (src/lib.rs:163): pinned host buffers,
+            # first H2D byte to last D2H byte inside the timed region
+            h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+            h_out = torch.empty(cap + 64, dtype=torch.uint8).pin_memory()
+            ctx.reserve(size, host_api=True)
+            ctx.encode_host_ptr(h_in.data_ptr(), size, h_out.data_ptr(), cap + 64, options)
+            reps = max(2, args.steps)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                hn = ctx.encode_host_ptr(h_in.data_ptr(), size, h_out.data_ptr(), cap + 64, options)
+            dt = time.perf_counter() - t1
+            res["value_host_api"] = {"value": round(size * reps / dt / 1e6, 2), "unit": "MB/s",
+                                     "ms_per_call": round(dt * 1e3 / reps, 3),
+                                     "what": "mi355_deflate_encode on pinned host buffers, H2D + encode + D2H",
+                                     "same_bytes": bool(hn == out_len[0])}
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
             olvl = {"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST, "rle": ob.RLE,
                     "huffman_only": ob.HUFFMAN_ONLY}[lvl]
-            sample = data
+            res["cpu_baseline"] = cpu_baselines(data, olvl, level_name)
+            # the whole workload once more through the oracle: the stream the GPU produced must be its stream
             t1 = time.perf_counter()
-            ref = ob.encode(sample, level=olvl)
-            dt = time.perf_counter() - t1
+            ref = ob.encode(data, level=olvl)
+            res["cpu_baseline"]["whole_workload_s"] = round(time.perf_counter() - t1, 2)
             got = bytes(d_out[: out_len[0]].cpu().numpy())
-            res["cpu_baseline"] = {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-                                   "sample": "the whole %d-byte workload, one pass of the single-threaded C++ "
-                                             "restatement of deflate-rs (oracle/), %.1f s" % (len(sample), dt)}
             res["ref_out_bytes"] = len(ref)
             res["bit_exact_vs_oracle"] = bool(got == ref)
         print(json.dumps(res))

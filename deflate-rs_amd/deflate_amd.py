@@ -231,6 +231,17 @@ class Context:
             self._err(rc)
         return bytes(memoryview(out)[: n.value])
 
+    def encode_host_ptr(self, in_ptr, in_len, out_ptr, out_cap, options=Compression.Default, wrapper=0):
+        """mi355_deflate_encode on raw host pointers (e.g. pinned buffers): H2D, encode, D2H; returns the length"""
+        L = load()
+        o = CompressionOptions.from_(options).to_c(wrapper, 0, 0)
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_encode(self._h, C.cast(C.c_void_p(in_ptr), C.c_char_p), in_len, C.byref(o),
+                                    C.cast(C.c_void_p(out_ptr), C.POINTER(C.c_uint8)), out_cap, C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return n.value
+
     def encode_gzip(self, data, options=Compression.Default, header=None, compat=0):
         """mi355_deflate_encode_gzip; header = GzBuilder::into_header() bytes (None: the blank one)."""
         L = load()
