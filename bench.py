@@ -234,6 +234,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    p1_trace = None
+    if shard_mode == "p1":  # one more step, untimed, with a device synchronisation after every phase
+        shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev, trace=True)
+        p1_trace = dict(shard.LAST_TRACE)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -293,6 +297,8 @@ def main():
                          "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes,
                          "input_load": input_load, "lds_bank_conflict_rate": lds_conflict},
         }
+        if p1_trace is not None:
+            res["p1_phases_ms_rank0"] = p1_trace  # (one untimed step, synchronised per phase)
         if world == 1:
             # the drop-in call itself, deflate_bytes(&[u8]) -> Vec<u8> (src/lib.rs:163): pinned host buffers,
             # first H2D byte to last D2H byte inside the timed region

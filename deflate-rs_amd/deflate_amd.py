@@ -162,6 +162,8 @@ def load():
     L.mi355_deflate_stream_take_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mi355_deflate_bound_ex.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]
     L.mi355_deflate_bound_ex.restype = C.c_size_t
+    L.mi355_checksum_combine.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.mi355_checksum_combine.restype = C.c_uint32
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_free.restype = None
@@ -181,7 +183,7 @@ EXPORTED = [
     "mi355_deflate_encode_gzip",
     "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
     "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
-    "mi355_shard_pack", "mi355_shard_end",
+    "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
 ]
 
 

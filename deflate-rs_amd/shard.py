@@ -156,25 +156,34 @@ def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
     return bytes(out[: (total_bits + 7) // 8].numpy())
 
 
-def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, compat=0, group=None, comm_device=None):
+LAST_TRACE = {}  # phase times (ms) of the last encode_p1_dist on this rank, when tracing is on
+
+
+def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, compat=0, group=None, comm_device=None,
+                   wrapper=0, gzip_header=None, trace=None):
     """One rank of the distributed driver.  d_ext: uint8 device tensor holding bytes [g_lo, g_hi) of the
     input (+ >= 16 bytes of slack).  comm_device: where exchanged tensors live -- the GPU for the nccl
-    (= RCCL) backend, "cpu" for gloo.  Returns (tensor on rank 0 | None, stream length in bytes)."""
+    (= RCCL) backend, "cpu" for gloo.  wrapper 1 / 2: a zlib / gzip stream (every rank sums its own range on
+    its GPU, rank 0 folds the sums and frames the stitched raw stream; lib.rs:182-198, 242-267).
+    Returns (tensor on rank 0 | None, stream length in bytes).
+
+    What travels, four rounds: (1) all-gather of the 576-entry exit tables, (2) all-gather
+    of the token counts while the up to 31 743 head tokens go to the left neighbour, (3) ONE all-gather of a
+    fixed-size record per rank -- block count, checksum, block costs -- after which every rank runs the same
+    serial plan and knows every rank's byte range, (4) the byte ranges to rank 0, whose receives are posted
+    before it packs its own blocks."""
+    import ctypes
+    import os
+    import time
+
+    import numpy as np
     import torch
     options = options if options is not None else da.Compression.Default
     dev = d_ext.device
     cdev = torch.device(comm_device) if comm_device is not None else dev
     L = layout
-
-    def gather_ints(vals):
-        mine = torch.tensor(vals, dtype=torch.int64, device=cdev)
-        allv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine, group=group)
-        return [t.tolist() for t in allv]
-
-    import os
-    import time
-    trace = os.environ.get("MI355_P1_TRACE") == "1"
+    if trace is None:
+        trace = os.environ.get("MI355_P1_TRACE") == "1"
     marks = []
 
     def mark(name):
@@ -185,90 +194,149 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     mark("start")
     sh = da.Shard(ctx, d_ext.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total, options, compat,
                   torch.cuda.current_stream(dev).cuda_stream)
-    mark("links+match+exit tables")
-    # exchange 1: exit tables -> entry positions
-    tables = gather_ints(sh.exit_table())
+    mark("chains, match table, exit tables")
+    # round 1: exit tables -> entry positions
+    mine = torch.tensor(sh.exit_table(), dtype=torch.int32, device=cdev)
+    allv = torch.empty(world * ZONE, dtype=torch.int32, device=cdev)
+    dist.all_gather_into_tensor(allv, mine, group=group)
+    tables = allv.view(world, ZONE).tolist()
     lays = [p1_layout(total, r, world) for r in range(world)]
     entries = p1_entries(lays, tables)
-    mark("x1 tables")
+    mark("x1 exit tables")
     n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
     mark("emit")
-    # exchange 2: token counts
-    counts = [c[0] for c in gather_ints([n_tok])]
-    skip, tail = p1_token_split(counts)
-    # exchange 3: the head tokens of rank r+1 complete the last block of rank r
-    ops = []  # (one group per rank: a send posted before the matching receive of the neighbour must not block it)
-    if rank > 0 and skip[rank]:
-        head = torch.empty(skip[rank], dtype=torch.int32, device=dev)
-        ctypes_copy_d2d(head.data_ptr(), tok_ptr, skip[rank] * 4)
+    # round 2: token counts; meanwhile the head of every rank's tokens is on its way to the left neighbour,
+    # which may need up to 31 743 of them to complete its last block (how many is known only with the counts)
+    head_n = min(n_tok, BLOCK_TOKENS - 1) if rank > 0 else 0
+    ops = []
+    if rank > 0:
+        head = torch.zeros(BLOCK_TOKENS - 1, dtype=torch.int32, device=dev)
+        if head_n:
+            ctypes_copy_d2d(head.data_ptr(), tok_ptr, head_n * 4)
         ops.append(dist.P2POp(dist.isend, head.to(cdev), rank - 1, group))
     tail_c = None
-    if tail[rank]:
-        tail_c = torch.empty(tail[rank], dtype=torch.int32, device=cdev)
+    if rank + 1 < world:
+        tail_c = torch.empty(BLOCK_TOKENS - 1, dtype=torch.int32, device=cdev)
         ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1, group))
-    for q in (dist.batch_isend_irecv(ops) if ops else []):
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    cnt = torch.tensor([n_tok], dtype=torch.int64, device=cdev)
+    allc_t = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(allc_t, cnt, group=group)
+    counts = allc_t.tolist()
+    skip, tail = p1_token_split(counts)
+    for q in reqs:
         q.wait()
-    tail_t = tail_c.to(dev) if tail_c is not None else None
-    import ctypes
-    import numpy as np
-    mark("x2+x3 counts, straddling tokens")
+    tail_t = tail_c[: tail[rank]].to(dev) if (tail_c is not None and tail[rank]) else None
+    mark("x2 counts + straddling tokens")
+    # this rank's checksum (its own range only), on its GPU -- before the block phase, whose device scalars
+    # the pack kernel still reads
+    csum = 0
+    own = L["hi"] - L["lo"]
+    if wrapper == 1:
+        csum = ctx.adler32_device(d_ext.data_ptr() + L["lo"], own)
+    elif wrapper == 2:
+        csum = ctx.crc32_device(d_ext.data_ptr() + L["lo"], own)
     nb, carr = sh.blocks_raw(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
-    # exchange 4: block costs (56 bytes per block) as raw bytes, padded to the largest rank; no per-block
-    # Python work anywhere on this path
     mark("block costs")
+    # round 3: one fixed-size record per rank: [block count, checksum, costs ...] as raw bytes
     csz = ctypes.sizeof(da.BlockCost)
-    nbs = [c[0] for c in gather_ints([nb])]
-    mx = max(1, max(nbs))
-    mine_c = torch.zeros(mx * csz, dtype=torch.uint8)
+    per = max((lay["b"] - lay["a"]) for lay in lays) // BLOCK_TOKENS + 3  # blocks a rank can own at most
+    rec = torch.zeros(16 + per * csz, dtype=torch.uint8)
+    rec[:16] = torch.from_numpy(np.array([nb, csum], dtype=np.int64).view(np.uint8))
     if nb:
-        mine_c[: nb * csz] = torch.from_numpy(np.frombuffer(carr, dtype=np.uint8, count=nb * csz).copy())
-    mine_c = mine_c.to(cdev)
-    allt = [torch.empty_like(mine_c) for _ in range(world)]
-    dist.all_gather(allt, mine_c, group=group)
-    flat = torch.cat([allt[r][: nbs[r] * csz] for r in range(world)]).cpu().numpy().tobytes()
+        if nb > per:
+            raise ValueError("rank %d owns %d blocks, more than its range can hold" % (rank, nb))
+        rec[16:16 + nb * csz] = torch.from_numpy(np.frombuffer(carr, dtype=np.uint8, count=nb * csz).copy())
+    rec = rec.to(cdev)
+    allr = torch.empty(world * rec.numel(), dtype=torch.uint8, device=cdev)
+    dist.all_gather_into_tensor(allr, rec, group=group)
+    allr = allr.cpu().view(world, -1).numpy()
+    hdrs = allr[:, :16].copy().view(np.int64)
+    nbs = [int(hdrs[r, 0]) for r in range(world)]
+    sums = [int(hdrs[r, 1]) & 0xFFFFFFFF for r in range(world)]
+    flat = b"".join(allr[r, 16:16 + nbs[r] * csz].tobytes() for r in range(world))
     ntot = sum(nbs)
     allc = (da.BlockCost * max(1, ntot)).from_buffer_copy(flat.ljust(csz, b"\0"))
-    mark("x4 costs")
+    mark("x3 costs")
     plans, total_bits = da.plan_blocks_raw(allc, ntot, compat)
     mark("plan")
-    b0 = sum(nbs[:rank])
+    stream_len = (total_bits + 7) // 8
+    # every rank's byte range follows from the plan (mi355_shard_pack: from the 32-bit word its first block
+    # starts in to the byte its last one ends in)
+    starts = [sum(nbs[:r]) for r in range(world)]
+    ranges = []
+    for r in range(world):
+        if not nbs[r]:
+            ranges.append((0, 0))
+            continue
+        e = plans[starts[r] + nbs[r]].bit_start if starts[r] + nbs[r] < ntot else total_bits
+        base = plans[starts[r]].bit_start // 32 * 32
+        ranges.append((base // 8, (e - base + 7) // 8))
+    b0 = starts[rank]
     end_bit = plans[b0 + nb].bit_start if b0 + nb < ntot else total_bits
+    # round 4: byte ranges to rank 0, all in flight at once (every peer has its own xGMI link to rank 0) and
+    # posted before rank 0 packs its own blocks; then OR-ed in: neighbours share the seam byte
+    hl = 0
+    out = None
+    tmps, reqs = {}, []
+    if rank == 0:
+        if wrapper == 1:
+            hl = 2
+        elif wrapper == 2:
+            gzip_header = bytes(gzip_header) if gzip_header is not None else da.BLANK_GZIP_HEADER
+            hl = len(gzip_header)
+        ops = []
+        for r in range(1, world):
+            f, k = ranges[r]
+            if k:
+                tmps[r] = torch.empty(k, dtype=torch.uint8, device=cdev)
+                ops.append(dist.P2POp(dist.irecv, tmps[r], r, group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        out = torch.zeros(hl + stream_len + 24, dtype=torch.uint8, device=dev)
     fb, nbytes = 0, 0
     dev_out = None
     if nb:
         cap = (end_bit - plans[b0].bit_start) // 8 + 64
         dev_out = torch.empty(cap, dtype=torch.uint8, device=dev)
         fb, nbytes = sh.pack_raw(plans, b0, end_bit, dev_out.data_ptr(), cap)
+        assert (fb, nbytes) == ranges[rank]
     mark("pack")
     sh.close()
-    # exchange 5: byte ranges to rank 0, all in flight at once (every peer has its own xGMI link to
-    # rank 0), then OR-ed in: neighbours share the seam byte
-    meta = gather_ints([fb, nbytes])
-    stream_len = (total_bits + 7) // 8
     if rank == 0:
-        out = torch.zeros(stream_len + 16, dtype=torch.uint8, device=dev)
         if nbytes:
-            out[fb:fb + nbytes] |= dev_out[:nbytes]
-        tmps, ops = {}, []
-        for r in range(1, world):
-            f, k = meta[r]
-            if k:
-                tmps[r] = torch.empty(k, dtype=torch.uint8, device=cdev)
-                ops.append(dist.P2POp(dist.irecv, tmps[r], r, group))
-        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            out[hl + fb:hl + fb + nbytes] |= dev_out[:nbytes]
+        for q in reqs:
             q.wait()
         for r, t in tmps.items():
-            f, k = meta[r]
-            out[f:f + k] |= t.to(dev)
-        mark("x5 stitch")
+            f, k = ranges[r]
+            out[hl + f:hl + f + k] |= t.to(dev)
+        n_out = hl + stream_len
+        if wrapper:
+            L_ = da.load()
+            acc = 1 if wrapper == 1 else 0
+            for r in range(world):
+                acc = L_.mi355_checksum_combine(wrapper, acc, sums[r], lays[r]["b"] - lays[r]["a"])
+            if wrapper == 1:  # zlib.rs:59-62, lib.rs:192-196
+                frame = torch.tensor([0x78, 0x9C], dtype=torch.uint8, device=dev)
+                trailer = torch.tensor(list(acc.to_bytes(4, "big")), dtype=torch.uint8, device=dev)
+            else:             # lib.rs:250-266
+                frame = torch.tensor(list(gzip_header), dtype=torch.uint8, device=dev)
+                trailer = torch.tensor(list(acc.to_bytes(4, "little")) + list((total & 0xFFFFFFFF).to_bytes(4, "little")),
+                                       dtype=torch.uint8, device=dev)
+            out[:hl] = frame
+            out[n_out:n_out + trailer.numel()] = trailer
+            n_out += trailer.numel()
+        mark("x4 stitch")
         if trace:
-            print("P1 rank 0 phases (ms): " + ", ".join("%s %.2f" % (marks[i][0], 1e3 * (marks[i][1] - marks[i - 1][1]))
-                                                      for i in range(1, len(marks))), flush=True)
-        return out[:stream_len], stream_len
+            LAST_TRACE.clear()
+            LAST_TRACE.update({marks[i][0]: round(1e3 * (marks[i][1] - marks[i - 1][1]), 3) for i in range(1, len(marks))})
+        return out[:n_out], n_out
     if nbytes:
         for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, dev_out[:nbytes].to(cdev).contiguous(), 0, group)]):
             q.wait()
-    return None, stream_len
+    tl = {1: 4, 2: 8}.get(wrapper, 0)
+    hl = {1: 2, 2: len(bytes(gzip_header) if gzip_header is not None else da.BLANK_GZIP_HEADER)}.get(wrapper, 0)
+    return None, stream_len + hl + tl
 
 
 def ctypes_copy_d2d(dst_ptr, src_ptr, nbytes):

@@ -191,6 +191,11 @@ int mi355_plan_blocks(const mi355_block_cost* costs, size_t n, uint32_t compat, 
 int mi355_shard_pack(mi355_shard* s, const mi355_block_info* plans, uint64_t end_bit, void* d_out, size_t out_cap,
                      uint64_t* first_byte, size_t* n_bytes);
 void mi355_shard_end(mi355_shard* s);
+/* A sharded zlib / gzip stream (deflate_bytes_zlib_conf, ZlibEncoder: src/lib.rs:182-198, src/checksum.rs:33-57):
+ * every rank sums its own byte range (mi355_adler32_device / mi355_crc32_device), rank 0 folds the sums in
+ * rank order with this and frames the stitched raw stream.  kind 1 = Adler-32, 2 = CRC-32;
+ * returns checksum(A || B) from checksum(A), checksum(B) and |B|. */
+uint32_t mi355_checksum_combine(int kind, uint32_t sum_a, uint32_t sum_b, uint64_t len_b);
 
 /* The gzip forms (cargo feature "gzip").  `hdr` = the bytes GzBuilder::into_header() returned: the
  * header comes from the crate gzip-header 1.0, which is not part of the reference tree, so the shim

@@ -393,11 +393,17 @@ def _p1_dist_worker(rank, world, port, q):
     L = shard.p1_layout(total, rank, world)
     d_ext = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).cuda()
     ctx = da.Context(0)
-    out, n = shard.encode_p1_dist(da, ctx, d_ext, L, total, rank, world, da.Compression.Default, compat=1,
-                                  comm_device="cpu")
+    ok = []
+    for wrapper in (0, 1, 2):  # raw; zlib and gzip: every rank sums its own range, rank 0 folds and frames
+        out, n = shard.encode_p1_dist(da, ctx, d_ext, L, total, rank, world, da.Compression.Default, compat=1,
+                                      comm_device="cpu", wrapper=wrapper)
+        if rank == 0:
+            import oracle_binding as ob2
+            ref = (ob2.encode_gzip(data, da.BLANK_GZIP_HEADER, level=ob2.DEFAULT) if wrapper == 2
+                   else ob2.encode(data, level=ob2.DEFAULT, wrapper=wrapper))
+            ok.append((wrapper, bytes(out.cpu().numpy()) == ref, n, len(ref)))
     if rank == 0:
-        import oracle_binding as ob2
-        q.put(bytes(out.cpu().numpy()) == ob2.encode(data, level=ob2.DEFAULT))
+        q.put(ok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -417,7 +423,7 @@ def test_p1_distributed_driver_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert ok
+    assert [x[:2] for x in ok] == [(0, True), (1, True), (2, True)] and all(x[2] == x[3] for x in ok), ok
 
 
 # flush() = Flush::Sync with window retention (writer.rs:134-137, 571-660; tests/test.rs:113-123
