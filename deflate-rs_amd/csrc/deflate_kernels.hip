@@ -696,64 +696,67 @@ struct SortWin {
     __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }  // (i may be -1: read ahead)
 };
 
-// M2_R chain steps (stages.h sw_step) for the lanes of `walk`, as one block of hand-scheduled code: the
-// lanes run under the execution mask, which only shrinks inside the block -- a lane whose candidate is
-// out of reach, passes the probe, or was the last of its run simply drops out and keeps its registers
-// for the service.  Per step: the candidate's probe bytes from LDS, the sorted array's entry two steps
-// ahead from global memory (three registers c / nx / nn rotate through the roles current, next, in
-// flight), three compares that write EXEC.  offb = 2 * off + 8 is the byte offset of the current
-// entry from sb8 = array base - 8 bytes (the offset register of a global load is unsigned).
-// Returns the lanes that are still walking.
-#define M2_STEP(C, N, L)                                \
-    "s_waitcnt vmcnt(1)\n\t"                            \
-    "v_add_u32_e32 %[a], " C ", %[bb]\n\t"              \
-    "ds_read_u8 %[t0], %[a]\n\t"                        \
-    "ds_read_u8 %[t1], %[a] offset:1\n\t"               \
-    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"            \
-    "global_load_ushort " L ", %[offb], %[sb] offset:-2\n\t" \
-    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"          \
-    "s_waitcnt lgkmcnt(0)\n\t"                          \
-    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"          \
-    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"        \
-    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"       \
+// M2_R chain steps (stages.h swl_steps_ref) for the lanes of `walk`, as one block of hand-scheduled code:
+// the lanes run under the execution mask, which only shrinks inside the block -- a lane whose candidate
+// is out of reach, passes the probe, or was the last of its run simply drops out and keeps its registers
+// for the service.  Per step: the candidate's two probe bytes from LDS and three compares that write EXEC.
+// The sorted array's entries come four at a time (one 8-byte load per lane and group of four steps, the
+// next group in flight meanwhile: a two-byte load per step kept the address unit busier than the vector
+// ALU); a step takes its entry as a 16-bit operand select (SDWA) of the group's registers, which are
+// fixed (v56..v59) because an operand cannot name the halves of a pair.  offb = 2 * off + 8 is the byte
+// offset of the current entry from sb8 = array base - 8 bytes (the offset register of a global load is
+// unsigned).  Returns the lanes that are still walking.
+#define M2_STEP(REG, HALF)                                                                     \
+    "v_add_u32_sdwa %[a], " REG ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t" \
+    "ds_read_u8 %[t0], %[a]\n\t"                                                               \
+    "ds_read_u8 %[t1], %[a] offset:1\n\t"                                                      \
+    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"                                                   \
+    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                 \
+    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"                                                 \
+    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"                                               \
+    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"                                              \
     "s_cbranch_execz .Lm2_end%=\n\t"
-static_assert(MI355_M2_R % 3 == 0, "the three read-ahead registers return to their roles every third step");
+// a group: entries off, off-1 in the high register (high half first), off-2, off-3 in the low one
+#define M2_GROUP(LO, HI) M2_STEP(HI, "WORD_1") M2_STEP(HI, "WORD_0") M2_STEP(LO, "WORD_1") M2_STEP(LO, "WORD_0")
+static_assert(MI355_M2_R % 4 == 0 && MI355_M2_R >= 8 && MI355_M2_R <= 16, "whole groups of four steps");
 
 __device__ __forceinline__ uint64_t m2_steps(uint32_t& offb, uint32_t& a, uint32_t& rv, uint32_t bb, uint32_t lowa,
                                              uint32_t probe, uint32_t endb, const uint16_t* sb8, uint64_t walk) {
-    uint32_t c, nx, nn, t1;
+    uint32_t t1;
     uint64_t save, still;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "s_mov_b64 exec, %[walk]\n\t"
-        "global_load_ushort %[c], %[offb], %[sb]\n\t"
-        "global_load_ushort %[nx], %[offb], %[sb] offset:-2\n\t"
-        M2_STEP("%[c]", "%[nx]", "%[nn]")
-        M2_STEP("%[nx]", "%[nn]", "%[c]")
-        M2_STEP("%[nn]", "%[c]", "%[nx]")
-#if MI355_M2_R >= 6
-        M2_STEP("%[c]", "%[nx]", "%[nn]")
-        M2_STEP("%[nx]", "%[nn]", "%[c]")
-        M2_STEP("%[nn]", "%[c]", "%[nx]")
-#endif
-#if MI355_M2_R >= 9
-        M2_STEP("%[c]", "%[nx]", "%[nn]")
-        M2_STEP("%[nx]", "%[nn]", "%[c]")
-        M2_STEP("%[nn]", "%[c]", "%[nx]")
-#endif
+        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"   // entries off-3 .. off
+        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"  // entries off-7 .. off-4
+        "s_waitcnt vmcnt(1)\n\t"
+        M2_GROUP("v56", "v57")
 #if MI355_M2_R >= 12
-        M2_STEP("%[c]", "%[nx]", "%[nn]")
-        M2_STEP("%[nx]", "%[nn]", "%[c]")
-        M2_STEP("%[nn]", "%[c]", "%[nx]")
+        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t"  // (offb has moved on by four entries)
+#endif
+        "s_waitcnt vmcnt(1)\n\t"
+        M2_GROUP("v58", "v59")
+#if MI355_M2_R >= 12
+#if MI355_M2_R >= 16
+        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+#else
+        "s_waitcnt vmcnt(0)\n\t"
+#endif
+        M2_GROUP("v56", "v57")
+#endif
+#if MI355_M2_R >= 16
+        "s_waitcnt vmcnt(0)\n\t"
+        M2_GROUP("v58", "v59")
 #endif
         ".Lm2_end%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "s_mov_b64 %[still], exec\n\t"
         "s_mov_b64 exec, %[save]\n\t"
-        : [c] "=&v"(c), [nx] "=&v"(nx), [nn] "=&v"(nn), [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1),
-          [save] "=&s"(save), [still] "=&s"(still)
+        : [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1), [save] "=&s"(save), [still] "=&s"(still)
         : [bb] "v"(bb), [lowa] "v"(lowa), [probe] "v"(probe), [endb] "v"(endb), [sb] "s"(sb8), [walk] "s"(walk)
-        : "vcc", "memory");
+        : "vcc", "memory", "v56", "v57", "v58", "v59");
     return still;
 }
 

@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     uint32_t R = argc > 4 ? atoi(argv[4]) : 8;
     int sort_by_cnt = argc > 5 ? atoi(argv[5]) : 0;
     uint32_t TH = argc > 6 ? atoi(argv[6]) : 1;  // service only when at least TH lanes wait (or none walks)
+    uint32_t MINW = argc > 7 ? atoi(argv[7]) : 0;  // ... or when fewer than MINW lanes still walk
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 1;
     std::vector<uint8_t> d(maxb + 8);
@@ -49,7 +50,22 @@ int main(int argc, char** argv) {
             cnt[i] = c;
             own.push_back((uint32_t)i);
         }
-        if (sort_by_cnt) std::stable_sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        if (sort_by_cnt == 1) std::stable_sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        if (sort_by_cnt == 2) {  // by the size class of the bucket within the own epoch (what k_sort can know)
+            std::vector<uint32_t> bsz(m, 0);
+            for (size_t i = 0; i < m;) {
+                size_t j = i;
+                uint32_t c = 0;
+                while (j < m && bstart[j] == bstart[i]) {
+                    c += ss[j] >= e * W;
+                    j++;
+                }
+                for (size_t k = i; k < j; k++) bsz[k] = c;
+                i = j;
+            }
+            auto cls = [&](uint32_t z) { return z >= 65 ? 0 : z >= 49 ? 1 : z >= 33 ? 2 : z >= 25 ? 3 : z >= 17 ? 4 : z >= 13 ? 5 : z >= 9 ? 6 : z >= 7 ? 7 : z >= 5 ? 8 : 13 - (int)z; };
+            std::stable_sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return cls(bsz[a]) < cls(bsz[b]); });
+        }
         for (size_t b0 = 0; b0 < own.size(); b0 += 64) {
             uint32_t nl = (uint32_t)std::min<size_t>(64, own.size() - b0);
             batches++;
@@ -100,7 +116,10 @@ int main(int argc, char** argv) {
                 }
                 uint32_t npend = 0;
                 for (uint32_t l = 0; l < nl; l++) npend += state[l] == 1;
-                bool serv = !anyw || ((step % R) == 0 && npend >= TH);
+                uint32_t nwalk = 0;
+                for (uint32_t l = 0; l < nl; l++) nwalk += state[l] == 0;
+                bool serv = !anyw || ((step % R) == 0 && npend >= TH) || (npend > 0 && nwalk < MINW);
+                if (serv) step = 0;
                 if (!serv) continue;
                 uint32_t np = 0, mr = 0;
                 for (uint32_t l = 0; l < nl; l++) {

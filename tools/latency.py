@@ -1,0 +1,27 @@
+"""Development aid (GPU box): wall-clock latency of one resident encode for small inputs."""
+import os, sys, time, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import datagen, deflate_amd as da
+ctx = da.Context(0)
+cases = [("pg11 167 KB", open(os.path.join(ROOT, "tests/golden/ref_inputs/pg11.txt"), "rb").read()),
+         ("text 2 MB", datagen.text_like(2_000_000, 2)), ("text 16 MB", datagen.text_like(16_000_000, 3)),
+         ("random 1 MB (Q1)", datagen.rng_bytes(1_000_000, 4))]
+for name, data in cases:
+    n = len(data)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = da.bound(n) + 8
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for lv in (da.Compression.Default, da.Compression.Fast):
+        for _ in range(3):
+            ctx.encode_device(t.data_ptr(), n, out.data_ptr(), cap, lv)
+        ws = []
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.encode_device(t.data_ptr(), n, out.data_ptr(), cap, lv)
+            ws.append((time.perf_counter() - t0) * 1e3)
+        i = ctx.info()
+        print("%-18s %-8s wall %.3f ms (min %.3f)  gpu events %.3f ms  stages %s" % (
+            name, lv.name, statistics.median(ws), min(ws), i["total_ms"], {k: round(v, 3) for k, v in i["stage_ms"].items()}))
