@@ -1613,6 +1613,11 @@ __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint6
 // whole words with plain stores; only the first and the last word of the wave's bit range, which it
 // shares with its neighbours, are OR-ed into the output.
 constexpr uint32_t PACK_WORDS = 256 * 48 / 32 + 4;
+#ifndef MI355_PACK_THREADS
+#define MI355_PACK_THREADS 256
+#endif
+constexpr uint32_t PKT = MI355_PACK_THREADS;  // threads of a k_pack workgroup (a block of 31744 tokens in 31744 / (4 PKT) rounds)
+constexpr uint32_t PKW = PKT / 64;
 __device__ __forceinline__ void put_bits_lds(uint32_t* buf, uint32_t bitpos, uint64_t bits, uint32_t nbits) {
     if (nbits == 0) return;
     const uint32_t w = bitpos >> 5, sh = bitpos & 31;
@@ -1633,10 +1638,10 @@ struct PackLds {
     uint8_t cll[20];   // code-length code lengths of a dynamic block
     uint32_t scan[256];
     uint32_t carry;
-    uint32_t wbuf[4][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
+    uint32_t wbuf[PKW][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
 };
 
-__global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, uint32_t n,
+__global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, uint32_t n,
                                               const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                               const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
             // the header or with the next block: OR.
             const uint64_t w0 = (ob + 3) >> 2, w1 = (ob + piece) >> 2;  // whole words [w0, w1)
             if (w1 > w0) {
-                for (uint64_t w = w0 + tid; w < w1; w += 256) {
+                for (uint64_t w = w0 + tid; w < w1; w += PKT) {
                     const uint64_t i = (w << 2) - ob;  // payload offset of the word's first byte
                     uint32_t v = 0;
 #pragma unroll
@@ -1675,14 +1680,14 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
                     out32[w] = v;
                 }
                 const uint64_t headn = (w0 << 2) - ob, tail0 = (w1 << 2) - ob;
-                for (uint64_t i = tid; i < headn + (piece - tail0); i += 256) {
+                for (uint64_t i = tid; i < headn + (piece - tail0); i += PKT) {
                     const uint64_t j = i < headn ? i : tail0 + (i - headn);
                     const uint64_t o = ob + j;
                     uint32_t v = (src + j < n) ? in[src + j] : 0u;
                     if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
                 }
             } else {
-                for (uint64_t i = tid; i < piece; i += 256) {
+                for (uint64_t i = tid; i < piece; i += PKT) {
                     uint64_t o = ob + i;
                     uint32_t v = (src + i < n) ? in[src + i] : 0u;
                     if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
@@ -1696,16 +1701,16 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
     }
     // code tables
     if (pl.btype == BT_FIXED) {
-        for (uint32_t i = tid; i < 288; i += 256) s.lll[i] = (uint8_t)fixed_ll_length(i);
+        for (uint32_t i = tid; i < 288; i += PKT) s.lll[i] = (uint8_t)fixed_ll_length(i);
         if (tid < 32) s.dl[tid] = 5;
     } else {
-        for (uint32_t i = tid; i < 288; i += 256) s.lll[i] = h->ll_len[i];
+        for (uint32_t i = tid; i < 288; i += PKT) s.lll[i] = h->ll_len[i];
         if (tid < 32) s.dl[tid] = h->d_len[tid];
     }
-    for (uint32_t i = tid; i < 288; i += 256) s.llc[i] = 0;
+    for (uint32_t i = tid; i < 288; i += PKT) s.llc[i] = 0;
     if (tid < 32) s.dc[tid] = 0;
     if (tid < 20) s.clc[tid] = 0;
-    for (uint32_t i = tid; i < 4 * PACK_WORDS; i += 256) (&s.wbuf[0][0])[i] = 0;
+    for (uint32_t i = tid; i < PKW * PACK_WORDS; i += PKT) (&s.wbuf[0][0])[i] = 0;
     __syncthreads();
     if (tid == 0) canonical_codes(s.lll, 288, s.llc);  // huffman_table.rs:253-278
     if (tid == 64) canonical_codes(s.dl, 32, s.dc);
@@ -1734,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
         }
         uint64_t hp = bp + 17 + 3ull * used;
         const uint32_t lane0 = tid & 63, wv0 = tid >> 6;
-        for (uint32_t i0 = 0; i0 < n_enc; i0 += 256) {
+        for (uint32_t i0 = 0; i0 < n_enc; i0 += PKT) {
             const uint32_t i = i0 + tid;
             uint64_t bits = 0;
             uint32_t nb2 = 0;
@@ -1764,7 +1769,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
             __syncthreads();
             uint32_t wbase = 0, total = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
+            for (uint32_t k = 0; k < PKW; k++) {
                 uint32_t y = s.scan[k];
                 if (k < wv0) wbase += y;
                 total += y;
@@ -1783,7 +1788,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
     const uint64_t t0 = tab.t0[b];
     const uint64_t t1 = t0 + tab.nt[b];
     const uint32_t lane = tid & 63, wv = tid >> 6;
-    for (uint64_t tb = t0; tb < t1; tb += 1024) {
+    for (uint64_t tb = t0; tb < t1; tb += 4 * PKT) {
         uint64_t tq = tb + 4ull * tid;
         uint32_t nb4[4];
         uint64_t bits4[4];
@@ -1805,7 +1810,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ in, ui
         __syncthreads();
         uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
+        for (uint32_t k = 0; k < PKW; k++) {
             uint32_t v = s.scan[k];
             if (k < wv) wbase += v;
             total += v;
