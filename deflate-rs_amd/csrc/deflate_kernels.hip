@@ -896,6 +896,165 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_match_coop: the wave-cooperative form of matching.rs:87-166 the north star describes -- ONE position
+// per wave, 64 lanes = 64 consecutive candidates of its chain (S makes the k-th candidate an array index),
+// probe and compare per lane, the first longest by ballot -- kept as a measured alternative
+// (MI355_MATCH_PATH=3; DESIGN.md has the numbers): a wave-instruction serves one position here and 64 of
+// them in k_match2, so it only pays where chains are hundreds of candidates long.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_Q>
+__global__ __launch_bounds__(M2T, 8) void k_match_coop(const uint8_t* __restrict__ in, uint32_t n,
+                                                       const uint16_t* __restrict__ Sg, const uint16_t* __restrict__ Bg,
+                                                       uint32_t* __restrict__ M, uint32_t* __restrict__ Mq, uint32_t checks,
+                                                       uint32_t checks_q, int in_aligned16, SegEnds sg, HashOverride ov,
+                                                       uint32_t e0) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_by[M2_BYTES];
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e = e0 + blockIdx.x;
+    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
+    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
+    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
+    uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_by);
+    for (uint32_t w = tid; w < wbytes / 4; w += M2T) {
+        const uint64_t g = wbase + 4ull * w;
+        uint32_t v = 0;
+        if (in_aligned16 && g + 4 <= n) {
+            v = *reinterpret_cast<const uint32_t*>(in + g);
+        } else {
+            for (int b = 0; b < 4; b++)
+                if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
+        }
+        sb32[w] = v;
+    }
+    const uint32_t J = epoch_active(n, E);
+    if (tid == 0) s_next = 0;
+    if (tid < 2) {
+        const uint64_t p = E + J + tid;
+        if (p < n && p < E + WINDOW_SIZE) {
+            M[p] = 0;
+            if (HAS_Q) Mq[p] = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t org = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_by;
+    const uint32_t bias = org + (uint32_t)(E - wbase);
+    SortWin win{Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE};
+    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
+    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
+    const uint16_t* Bprev = Bown - BSTRIDE;
+    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
+    for (uint32_t guard_o = 0; guard_o < 40000; guard_o++) {
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+        if (j >= J) break;
+        // everything about the position is the same in all lanes
+        const uint32_t srel = own[j];
+        const uint32_t prel = bias + srel;
+        const uint32_t v = win.load32(prel);
+        const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
+        const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
+        const uint32_t nrel = org + lim(prel - org);
+        uint32_t m = 0, mq = 0;
+        bool hq = HAS_Q && checks_q == 0;
+        if (prel + 2 < nrel && checks > 0) {
+            const uint32_t left0 = nrel - prel;
+            const uint32_t maxlen = left0 < (uint32_t)MAX_MATCH ? left0 : (uint32_t)MAX_MATCH;
+            const uint32_t low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
+            uint32_t p16[4];
+            win.load128(prel, p16);
+            uint32_t best = 1, bestd = 0, probe = p16[0] & 0xffffu;
+            uint32_t left = checks, qleft = checks_q;
+            bool done = false;
+            for (int phase = 0; phase < 2 && !done && left; phase++) {
+                int32_t top, lo;       // candidate indices top, top-1, ..., lo of this phase
+                uint32_t cb;           // coordinate of the phase's epoch
+                if (phase == 0) {
+                    top = (int32_t)(SW_OWN + j) - 1;
+                    lo = (int32_t)(SW_OWN + Bown[h]);
+                    cb = bias;
+                } else {
+                    if (!e) break;
+                    top = (int32_t)Bprev[h + 1] - 1;
+                    lo = (int32_t)Bprev[h];
+                    cb = org;
+                }
+                uint32_t guard_w = 0;
+                while (top >= lo && left && !done && ++guard_w < 4096) {
+                    uint32_t take = (uint32_t)(top - lo + 1);
+                    take = take < 64 ? take : 64;
+                    take = take < left ? take : left;
+                    if (HAS_Q && !hq) take = take < qleft ? take : qleft;
+                    const bool mine = lane < take;
+                    const uint32_t c = mine ? cb + win.sidx((uint32_t)(top - (int32_t)lane)) : prel;
+                    const bool inwin = mine && c >= low;  // matching.rs:102-106,127
+                    const uint64_t wmask = __builtin_amdgcn_ballot_w64(inwin);
+                    const bool hit = inwin && (win.load32(c + best - 1) & 0xffffu) == probe;  // :141-143
+                    uint32_t len = 0;
+                    if (__builtin_amdgcn_ballot_w64(hit)) {
+                        if (hit) {  // get_match_length :67-72
+                            uint32_t q[4];
+                            win.load128(c, q);
+                            const uint64_t z0 = ((uint64_t)(q[1] ^ p16[1]) << 32) | (uint64_t)(q[0] ^ p16[0]);
+                            const uint64_t z1 = ((uint64_t)(q[3] ^ p16[3]) << 32) | (uint64_t)(q[2] ^ p16[2]);
+                            len = z0 ? ((uint32_t)__builtin_ctzll(z0) >> 3) : (z1 ? 8u + ((uint32_t)__builtin_ctzll(z1) >> 3) : 16u);
+                            uint32_t guard_l = 0;
+                            while (len >= 16 && len < maxlen && ++guard_l < 64) {
+                                const uint64_t x = ((uint64_t)(win.load32(prel + len + 4) ^ win.load32(c + len + 4)) << 32) |
+                                                   (uint64_t)(win.load32(prel + len) ^ win.load32(c + len));
+                                if (x) {
+                                    len += (uint32_t)__builtin_ctzll(x) >> 3;
+                                    break;
+                                }
+                                len += 8;
+                            }
+                            len = len < maxlen ? len : maxlen;
+                        }
+                        // the longest of the chunk, the first (most recent) among equals: matching.rs:149-156
+                        uint32_t mx = len;
+#pragma unroll
+                        for (int off = 32; off; off >>= 1) {
+                            const uint32_t y = __shfl_xor(mx, off, 64);
+                            mx = mx > y ? mx : y;
+                        }
+                        if (mx > best) {
+                            const uint64_t who = __builtin_amdgcn_ballot_w64(hit && len == mx);
+                            const uint32_t first = (uint32_t)__builtin_ctzll(who);
+                            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)first);
+                            best = mx;
+                            bestd = prel - cc;
+                            if (mx == maxlen) {
+                                // (the reference stops at this candidate; candidates after it in the chunk were never visited)
+                                done = true;
+                            } else {
+                                probe = win.load32(prel + best - 1) & 0xffffu;
+                            }
+                        }
+                    }
+                    // a candidate out of the window ends the chain
+                    if (wmask != (take == 64 ? ~0ull : ((1ull << take) - 1ull))) done = true;
+                    left -= take;
+                    if (HAS_Q && !hq) {
+                        qleft -= take;
+                        if (qleft == 0 && !done) {  // lz77.rs:351-355 (the walk goes on: not the final result)
+                            mq = m_pack(bestd ? best : 0, bestd);
+                            hq = true;
+                        }
+                    }
+                    top -= (int32_t)take;
+                }
+            }
+            m = m_pack(bestd ? best : 0, bestd);
+        }
+        if (lane == 0) {
+            M[E + srel] = m;
+            if (HAS_Q) Mq[E + srel] = hq ? mq : m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_rle: rle.rs:13-18 get_match_length_rle for every position: R[p] = run of data[p-1]
 // starting at p, capped at 258 and at the end of input.  Each lane owns 16 consecutive
 // positions: one forward scan of at most 258 bytes past its chunk, then a backward recurrence.
