@@ -867,7 +867,7 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         }
         const uint64_t start = __builtin_amdgcn_ballot_w64(search);
         st.done = ~start;
-        swl_service(st, win, org, (uint64_t)0, start);
+        swl_start(st, org, start);
         M2_CNT(0, 1)
         M2_T(8)
         for (;;) {

@@ -917,6 +917,32 @@ MI355_HD void swl_service(SwLean<HAS_Q>& s, const W& w, uint32_t org, lane_flag 
     s.walk = lf_and_not(s.walk | resume | go, s.done);
 }
 
+// The first run of the lanes in `start` (the run part of swl_service alone: a lane that has not walked yet
+// has nothing to compare).
+template <bool HAS_Q>
+MI355_HD void swl_start(SwLean<HAS_Q>& s, uint32_t org, lane_flag start) {
+    const int32_t av1 = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
+    const lane_flag same = start & lf_of(av1 > 0 && s.left > 0);
+    const lane_flag sw = lf_and_not(start, same) & lf_of(s.left > 0 && (int32_t)s.offb2 >= (int32_t)s.lob2);
+    s.done = s.done | lf_and_not(lf_and_not(start, same), sw);
+    s.offb = lf_me(sw) ? s.offb2 : s.offb;
+    s.lob = lf_me(sw) ? s.lob2 : s.lob;
+    s.bb = lf_me(sw) ? s.bm1 + org : s.bb;
+    s.in_prev = s.in_prev | sw;
+    const lane_flag go = same | sw;
+    const int32_t av = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
+    uint32_t r = (uint32_t)av < s.left ? (uint32_t)av : s.left;
+    if (HAS_Q) r = (lf_me(s.hq) || r < s.qleft) ? r : s.qleft;
+    r = lf_me(go) ? r : 0u;
+    s.endb = lf_me(go) ? s.offb + 2 - 2 * r : s.endb;
+    s.left -= r;
+    if (HAS_Q) s.qleft -= lf_me(s.hq) ? 0u : r;
+    const lane_flag fin = lf_of(!(s.left > 0 && ((int32_t)s.endb > (int32_t)s.lob ||
+                                                 (!lf_me(s.in_prev) && (int32_t)s.offb2 >= (int32_t)s.lob2))));
+    s.final = lf_and_not(s.final, go) | (go & fin);
+    s.walk = lf_and_not(go, s.done);
+}
+
 // Set a lane up for entry j of its epoch's array (see sw_setup); the first service call starts its run.
 // Returns whether the position is searched at all.
 template <bool HAS_Q, class W>

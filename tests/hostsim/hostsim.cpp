@@ -149,7 +149,10 @@ void stage_match(Sim& s) {
                 auto run5 = [&](auto& ln) {  // the predicated form k_match2 runs: block of steps, one service
                     const bool search = swl_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
                     ln.done = lf_of(!search);
-                    swl_service(ln, win, 0u, lf_of(false), lf_of(search));
+                    if (j & 1)  // (both ways of starting a lane)
+                        swl_service(ln, win, 0u, lf_of(false), lf_of(search));
+                    else
+                        swl_start(ln, 0u, lf_of(search));
                     uint32_t guard = 0;
                     while (lf_me(ln.walk)) {
                         swl_steps_ref(ln, win, 3 + (guard % 4) * 3);
