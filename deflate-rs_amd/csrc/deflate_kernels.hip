@@ -1112,13 +1112,29 @@ struct TileM {
 };
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                              ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg) {
-    __shared__ uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
+    __shared__ __attribute__((aligned(16))) uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
     const uint64_t t0 = (uint64_t)blockIdx.x * ADV_TILE;
     const bool useq = Mq != nullptr;
-    for (uint32_t i = threadIdx.x; i < ADV_TILE + ADV_HALO; i += 256) {  // (the tables are padded by 64 entries)
+    // (the tables are padded by 64 entries and 256-byte aligned, a tile starts at a multiple of 1024 entries:
+    // sixteen bytes per lane)
+    for (uint32_t i = threadIdx.x * 4; i < ADV_TILE + ADV_HALO; i += 1024) {
         const uint64_t g = t0 + i;
-        sM[i] = g < (uint64_t)n + 64 ? M[g] : 0u;
-        if (useq) sQ[i] = g < (uint64_t)n + 64 ? Mq[g] : 0u;
+        uint4 v = make_uint4(0, 0, 0, 0), q = make_uint4(0, 0, 0, 0);
+        if (g + 4 <= (uint64_t)n + 64) {
+            v = *reinterpret_cast<const uint4*>(M + g);
+            if (useq) q = *reinterpret_cast<const uint4*>(Mq + g);
+        } else {
+            uint32_t t[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; k++)
+                if (g + k < (uint64_t)n + 64) {
+                    t[k] = M[g + k];
+                    if (useq) u[k] = Mq[g + k];
+                }
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+            q = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        *reinterpret_cast<uint4*>(sM + i) = v;
+        if (useq) *reinterpret_cast<uint4*>(sQ + i) = q;
     }
     __syncthreads();
     // four consecutive positions per lane, one 8-byte store of adv
