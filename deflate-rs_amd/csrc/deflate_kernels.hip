@@ -884,6 +884,9 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         if (valid) {
             uint32_t m, mq;
             swl_result(st, &m, &mq);
+#ifdef MI355_M2_NOSTORE  // (timing experiment: what the scattered stores of M cost)
+            if (m == 0xFFFFFFFFu)
+#endif
             M[E + srel] = m;
             if (HAS_Q) Mq[E + srel] = mq;
         }
