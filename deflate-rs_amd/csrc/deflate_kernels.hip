@@ -677,6 +677,25 @@ constexpr uint32_t M2_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
 struct SortWin {
     const uint16_t* sb;   // global: index 0 = entry 0 of the previous epoch's sorted array
     // byte coordinates are LDS addresses
+    // gfx950 reads LDS at any byte address (ds_read_u16 / _b32 / _b128 return the right bytes,
+    // tools/probes/lds_unaligned.hip), but misaligned reads are slow.  Measured on the bench input: these
+    // two loads as single unaligned reads, match stage 4.18 -> 5.54 ms; the step's probe as one ds_read_u16
+    // instead of two ds_read_u8 (MI355_LDS_UNALIGNED_STEP), 4.18 -> 8.19 ms.  Hence aligned dwords and
+    // v_alignbyte here, and byte reads in the step.
+#ifdef MI355_LDS_UNALIGNED_LOADS
+    __device__ uint32_t load32(uint32_t i) const {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        return *(__attribute__((address_space(3))) const u32u*)i;
+    }
+    __device__ void load128(uint32_t i, uint32_t* q) const {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        const __attribute__((address_space(3))) u32u* p = (const __attribute__((address_space(3))) u32u*)i;
+        q[0] = p[0];
+        q[1] = p[1];
+        q[2] = p[2];
+        q[3] = p[3];
+    }
+#else
     __device__ uint32_t load32(uint32_t i) const {
         typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
         lds_u32 w = (lds_u32)(i & ~3u);
@@ -693,6 +712,7 @@ struct SortWin {
         q[2] = __builtin_amdgcn_alignbyte(d3, d2, i);
         q[3] = __builtin_amdgcn_alignbyte(d4, d3, i);
     }
+#endif
     __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }  // (i may be -1: read ahead)
 };
 
@@ -706,14 +726,24 @@ struct SortWin {
 // fixed (v56..v59) because an operand cannot name the halves of a pair.  offb = 2 * off + 8 is the byte
 // offset of the current entry from sb8 = array base - 8 bytes (the offset register of a global load is
 // unsigned).  Returns the lanes that are still walking.
+#ifdef MI355_LDS_UNALIGNED_STEP
+#define M2_PROBE                                      \
+    "ds_read_u16 %[t0], %[a]\n\t"                     \
+    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"          \
+    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"        \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#else
+#define M2_PROBE                                      \
+    "ds_read_u8 %[t0], %[a]\n\t"                      \
+    "ds_read_u8 %[t1], %[a] offset:1\n\t"             \
+    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"          \
+    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"        \
+    "s_waitcnt lgkmcnt(0)\n\t"                        \
+    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"
+#endif
 #define M2_STEP(REG, HALF)                                                                     \
     "v_add_u32_sdwa %[a], " REG ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t" \
-    "ds_read_u8 %[t0], %[a]\n\t"                                                               \
-    "ds_read_u8 %[t1], %[a] offset:1\n\t"                                                      \
-    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"                                                   \
-    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"                                                 \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                 \
-    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"                                                 \
+    M2_PROBE                                                                                   \
     "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"                                               \
     "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"                                              \
     "s_cbranch_execz .Lm2_end%=\n\t"
@@ -884,9 +914,6 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         if (valid) {
             uint32_t m, mq;
             swl_result(st, &m, &mq);
-#ifdef MI355_M2_NOSTORE  // (timing experiment: what the scattered stores of M cost)
-            if (m == 0xFFFFFFFFu)
-#endif
             M[E + srel] = m;
             if (HAS_Q) Mq[E + srel] = mq;
         }
@@ -1526,19 +1553,30 @@ __global__ __launch_bounds__(256) void k_block_table_uniform(uint64_t T2, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_block_hist: output_writer.rs:47-65,75-85 -- literal/length and distance frequencies of one
-// block, reduced in LDS.
+// k_block_hist: output_writer.rs:47-65,75-85 -- literal/length and distance frequencies, reduced in
+// LDS.  A block's tokens are cut into PSPLIT parts of PQ tokens; every part gets a workgroup and its own
+// histogram (the end-of-block symbol, output_writer.rs:83, is added by the reader): the block's
+// frequencies are the sum of the parts, and the parts' sums of code lengths tell k_pack where each
+// part's bits begin.
 // ---------------------------------------------------------------------------------------------
+#ifndef MI355_PACK_SPLIT
+#define MI355_PACK_SPLIT 4
+#endif
+constexpr uint32_t PSPLIT = MI355_PACK_SPLIT;
+constexpr uint32_t PQ = MAX_BUFFER_LENGTH / PSPLIT;  // tokens of a part
+static_assert(MAX_BUFFER_LENGTH % PSPLIT == 0, "parts of equal size");
+
 __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                                     uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq,
                                                     BlockTab tab) {
     __shared__ uint32_t h[320];
-    uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
     if (b >= sc->nb) return;
     for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
     __syncthreads();
-    uint64_t t0 = tab.t0[b];
-    uint64_t t1 = t0 + tab.nt[b];
+    const uint32_t nt = tab.nt[b];
+    const uint64_t t0 = (uint64_t)tab.t0[b] + (uint64_t)q * PQ;
+    const uint64_t t1 = (uint64_t)tab.t0[b] + ((q + 1) * PQ < nt ? (q + 1) * PQ : nt);
     for (uint64_t t = t0 + threadIdx.x; t < t1; t += 256) {
         uint32_t tk = dtok[t];
         if (tk >> 16) {
@@ -1552,10 +1590,9 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) h[END_OF_BLOCK] += 1;  // output_writer.rs:83
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 288; i += 256) ll_freq[(uint64_t)b * 288 + i] = i < NUM_LL ? h[i] : 0;
-    for (uint32_t i = threadIdx.x; i < 32; i += 256) d_freq[(uint64_t)b * 32 + i] = i < NUM_DIST ? h[288 + i] : 0;
+    const uint64_t slot = (uint64_t)b * PSPLIT + q;
+    for (uint32_t i = threadIdx.x; i < 288; i += 256) ll_freq[slot * 288 + i] = i < NUM_LL ? h[i] : 0;
+    for (uint32_t i = threadIdx.x; i < 32; i += 256) d_freq[slot * 32 + i] = i < NUM_DIST ? h[288 + i] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1608,8 +1645,16 @@ __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const
     __shared__ HdrLds s;
     uint32_t b = blockIdx.x, lane = threadIdx.x;
     if (b >= sc->nb) return;
-    for (uint32_t i = lane; i < 288; i += 64) s.llf[i] = ll_freq[(uint64_t)b * 288 + i];
-    if (lane < 32) s.df[lane] = d_freq[(uint64_t)b * 32 + lane];
+    for (uint32_t i = lane; i < 288; i += 64) {
+        uint32_t f = i == END_OF_BLOCK ? 1u : 0u;  // output_writer.rs:83
+        for (uint32_t q = 0; q < PSPLIT; q++) f += ll_freq[((uint64_t)b * PSPLIT + q) * 288 + i];
+        s.llf[i] = f;
+    }
+    if (lane < 32) {
+        uint32_t f = 0;
+        for (uint32_t q = 0; q < PSPLIT; q++) f += d_freq[((uint64_t)b * PSPLIT + q) * 32 + lane];
+        s.df[lane] = f;
+    }
     if (lane < 19) s.clf[lane] = 0;
     __syncthreads();
     if (lane == 0) {
@@ -1814,6 +1859,7 @@ struct PackLds {
     uint8_t lll[288];
     uint8_t dl[32];
     uint8_t cll[20];   // code-length code lengths of a dynamic block
+    uint32_t cnt[48];   // canonical codes: symbols per code length, then first code per length; [table][16]
     uint32_t scan[256];
     uint32_t carry;
     uint32_t wbuf[PKW][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
@@ -1823,10 +1869,13 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
                                               const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                               const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
-                                              uint32_t compat, uint32_t* __restrict__ out32, BlockTab tab) {
+                                              uint32_t compat, uint32_t* __restrict__ out32, BlockTab tab,
+                                              const uint32_t* __restrict__ ll_freq, const uint32_t* __restrict__ d_freq) {
     __shared__ PackLds s;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT, tid = threadIdx.x;
     if (b >= sc->nb) return;
+    const uint32_t gtid = part * PKT + tid;  // a stored block's bytes are spread over all parts' threads
+    constexpr uint32_t GT = PKT * PSPLIT;
     const BlockPlan pl = plan[b];
     const BlockHeader* h = hdr + b;
     uint64_t bp = pl.bit_start;
@@ -1839,7 +1888,7 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
             uint64_t piece = left < (uint64_t)MAX_STORED_BLOCK_LENGTH ? left : (uint64_t)MAX_STORED_BLOCK_LENGTH;
             bool last_piece = piece == left;
             uint64_t hb = (bp + 3 + 7) & ~7ull;  // header bits then pad to a byte
-            if (tid == 0) {
+            if (gtid == 0) {
                 put_bits(out32, bp, (pl.bfinal && last_piece) ? 1u : 0u, 3);
                 put_bits(out32, hb, (piece & 0xffff) | (((~piece) & 0xffff) << 16), 32);
             }
@@ -1850,7 +1899,7 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
             // the header or with the next block: OR.
             const uint64_t w0 = (ob + 3) >> 2, w1 = (ob + piece) >> 2;  // whole words [w0, w1)
             if (w1 > w0) {
-                for (uint64_t w = w0 + tid; w < w1; w += PKT) {
+                for (uint64_t w = w0 + gtid; w < w1; w += GT) {
                     const uint64_t i = (w << 2) - ob;  // payload offset of the word's first byte
                     uint32_t v = 0;
 #pragma unroll
@@ -1858,14 +1907,14 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
                     out32[w] = v;
                 }
                 const uint64_t headn = (w0 << 2) - ob, tail0 = (w1 << 2) - ob;
-                for (uint64_t i = tid; i < headn + (piece - tail0); i += PKT) {
+                for (uint64_t i = gtid; i < headn + (piece - tail0); i += GT) {
                     const uint64_t j = i < headn ? i : tail0 + (i - headn);
                     const uint64_t o = ob + j;
                     uint32_t v = (src + j < n) ? in[src + j] : 0u;
                     if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
                 }
             } else {
-                for (uint64_t i = tid; i < piece; i += PKT) {
+                for (uint64_t i = gtid; i < piece; i += GT) {
                     uint64_t o = ob + i;
                     uint32_t v = (src + i < n) ? in[src + i] : 0u;
                     if (v) atomicOr(out32 + (o >> 2), v << (8 * (o & 3)));
@@ -1877,6 +1926,8 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
         } while (left > 0);
         return;
     }
+    const uint32_t nt = tab.nt[b];
+    if (part > 0 && part * PQ >= nt) return;  // (an empty block is part 0's)
     // code tables
     if (pl.btype == BT_FIXED) {
         for (uint32_t i = tid; i < 288; i += PKT) s.lll[i] = (uint8_t)fixed_ll_length(i);
@@ -1885,25 +1936,83 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
         for (uint32_t i = tid; i < 288; i += PKT) s.lll[i] = h->ll_len[i];
         if (tid < 32) s.dl[tid] = h->d_len[tid];
     }
-    for (uint32_t i = tid; i < 288; i += PKT) s.llc[i] = 0;
-    if (tid < 32) s.dc[tid] = 0;
-    if (tid < 20) s.clc[tid] = 0;
+    if (tid < 20) s.cll[tid] = (pl.btype == BT_DYNAMIC && tid < 19) ? h->cl_len[tid] : 0;
+    if (tid < 48) s.cnt[tid] = 0;
     for (uint32_t i = tid; i < PKW * PACK_WORDS; i += PKT) (&s.wbuf[0][0])[i] = 0;
     __syncthreads();
-    if (tid == 0) canonical_codes(s.lll, 288, s.llc);  // huffman_table.rs:253-278
-    if (tid == 64) canonical_codes(s.dl, 32, s.dc);
-    if (tid == 128 && pl.btype == BT_DYNAMIC) canonical_codes(h->cl_len, 19, s.clc);  // (19 loads; the lists above are longer)
+    // Canonical codes (huffman_table.rs:253-278; stages.h canonical_codes is the serial form) for the three
+    // tables at once: symbols per length by LDS atomics, first code of every length by one thread per table,
+    // then symbol i takes the first code of its length plus the number of symbols before it with that length.
+    for (uint32_t i = tid; i < 288; i += PKT)
+        if (s.lll[i]) atomicAdd(&s.cnt[s.lll[i]], 1u);
+    if (tid < 32 && s.dl[tid]) atomicAdd(&s.cnt[16 + s.dl[tid]], 1u);
+    if (tid < 19 && s.cll[tid]) atomicAdd(&s.cnt[32 + s.cll[tid]], 1u);
+    __syncthreads();
+    if (tid < 3) {
+        uint32_t* c = s.cnt + 16 * tid;
+        uint32_t code = 0, before = 0;  // (no symbol is counted under length 0)
+        for (uint32_t bits = 1; bits < 16; bits++) {
+            code = ((code + before) << 1) & 0xffff;
+            before = c[bits];
+            c[bits] = code;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 288 + 32 + 20; i += PKT) {
+        const uint8_t* len = i < 288 ? s.lll : (i < 320 ? s.dl : s.cll);
+        uint16_t* codes = i < 288 ? s.llc : (i < 320 ? s.dc : s.clc);
+        const uint32_t* first = s.cnt + (i < 288 ? 0 : (i < 320 ? 16 : 32));
+        const uint32_t k = i < 288 ? i : (i < 320 ? i - 288 : i - 320);
+        const uint32_t l = len[k];
+        uint32_t r = 0;
+        if (l)
+            for (uint32_t j = 0; j < k; j++) r += len[j] == l ? 1u : 0u;
+        codes[k] = l ? (uint16_t)reverse_bits16((first[l] + r) & 0xffff, l) : (uint16_t)0;
+    }
     __syncthreads();
     // block header
     uint32_t hdr_bits = 3;
-    if (pl.btype == BT_DYNAMIC) {
+    if (part > 0) {
+        // Where this part's bits begin: behind the header and the tokens of the parts before it, whose sizes
+        // follow from their histograms (code length + extra bits per symbol).  A dynamic header is what is
+        // left of dyn_bits (stages.h block_costs) after all the symbols.
+        uint32_t pre = 0, all = 0;
+        for (uint32_t i = tid; i < 320; i += PKT) {
+            uint32_t len = 0;
+            if (i < NUM_LL) len = s.lll[i] + (i >= 257 ? length_extra_bits_of_code(i - 257) : 0u);
+            if (i >= 288 && i - 288 < NUM_DIST) len = s.dl[i - 288] + distance_extra_bits_of_code(i - 288);
+            for (uint32_t k = 0; k < PSPLIT; k++) {
+                const uint64_t slot = (uint64_t)b * PSPLIT + k;
+                const uint32_t f = i < 288 ? ll_freq[slot * 288 + i] : d_freq[slot * 32 + (i - 288)];
+                all += f * len;
+                if (k < part) pre += f * len;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            pre += __shfl_xor(pre, off);
+            all += __shfl_xor(all, off);
+        }
+        if ((tid & 63) == 0) {
+            s.scan[tid >> 6] = pre;
+            s.scan[PKW + (tid >> 6)] = all;
+        }
+        __syncthreads();
+        pre = 0;
+        all = 0;
+        for (uint32_t k = 0; k < PKW; k++) {
+            pre += s.scan[k];
+            all += s.scan[PKW + k];
+        }
+        __syncthreads();
+        hdr_bits = 3 + pre;
+        if (pl.btype == BT_DYNAMIC) hdr_bits += (uint32_t)(h->dyn_bits - all - s.lll[END_OF_BLOCK]);
+    } else if (pl.btype == BT_DYNAMIC) {
         // 3 + 14 bits, the code-length code lengths (huffman_lengths.rs:329-331), then the run-length
         // coded lengths (:338-368), one symbol per thread: bit strings, a scan of their lengths over
         // the workgroup, OR into the output.  (One lane walking the list would wait for two dependent
         // loads from the header in global memory per symbol.)
         const uint32_t used = h->used_hclens, n_enc = h->n_enc;
-        if (tid < 19) s.cll[tid] = h->cl_len[tid];
-        __syncthreads();
         if (tid == 0) {
             uint64_t p = bp;
             put_bits(out32, p, pl.bfinal ? 5u : 4u, 3);  // encoder_state.rs:12-13
@@ -1963,8 +2072,8 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
     bp += hdr_bits;
     // tokens: 4 consecutive tokens per lane and round; lengths are scanned inside the wave with
     // shuffles and across the 4 waves through LDS (two barriers per 1024 tokens)
-    const uint64_t t0 = tab.t0[b];
-    const uint64_t t1 = t0 + tab.nt[b];
+    const uint64_t t0 = (uint64_t)tab.t0[b] + (uint64_t)part * PQ;
+    const uint64_t t1 = (uint64_t)tab.t0[b] + ((part + 1) * PQ < nt ? (part + 1) * PQ : nt);
     const uint32_t lane = tid & 63, wv = tid >> 6;
     for (uint64_t tb = t0; tb < t1; tb += 4 * PKT) {
         uint64_t tq = tb + 4ull * tid;
@@ -2017,7 +2126,7 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
         bp += total;
         __syncthreads();
     }
-    if (tid == 0) put_bits(out32, bp, s.llc[END_OF_BLOCK], s.lll[END_OF_BLOCK]);  // encoder_state.rs:102-105
+    if (tid == 0 && (part + 1) * PQ >= nt) put_bits(out32, bp, s.llc[END_OF_BLOCK], s.lll[END_OF_BLOCK]);  // encoder_state.rs:102-105
 }
 
 // ---------------------------------------------------------------------------------------------
