@@ -1596,19 +1596,29 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_block_header: huffman_lengths.rs:167-266 for one block per wave: three length-limited
-// Huffman codes (length_encode.rs:347-415), the run-length coded table (length_encode.rs:82-155)
-// and the cost figures.  The sort is a 64-lane rank sort on (freq << 9 | symbol), which equals
-// the reference's stable sort by freq; the Moffat-Katajainen passes and the limiter run in
-// lane 0 on LDS arrays.
+// k_block_header: huffman_lengths.rs:167-266 for one block per wave: three length-limited Huffman codes
+// (length_encode.rs:347-415), the run-length coded table (length_encode.rs:82-155) and the cost figures.
+// All blocks run at once, so the kernel takes as long as one block does: what can be spread over the
+// wave is (stages.h huff_lengths_sorted is the serial form the host twin runs) --
+//   used symbols: ballot compaction; sort: 64-lane rank sort on (freq << 9 | symbol), which equals the
+//   reference's stable sort by freq; Moffat-Katajainen phase 1 (the two-queue merge, :218-247): one lane,
+//   the heads of both queues in registers; depths of the internal nodes (:249-252): pointer jumping over
+//   (depth, parent) words instead of the serial sweep; leaves per depth (:253-278): from the histogram of
+//   the internal depths, level by level; limiter: limit_code_lengths on the LDS histogram; hand-out
+//   (:402-408): every lane finds the length of its rank by a walk over the 15 counts; costs: a wave sum.
+// Local arrays with a dynamic index would live in scratch memory (one round trip to L2 per access): all
+// tables are in LDS.
 // ---------------------------------------------------------------------------------------------
 struct HdrLds {
     uint32_t llf[288];
     uint32_t df[32];
-    uint32_t clf[19];
-    uint32_t m;
+    uint32_t clf[20];
     HuffNode nodes[288];
-    HuffNode sorted[288];
+    uint32_t val[288];   // sorted frequencies -> Moffat-Katajainen working array
+    uint32_t sym[288];   // symbol of every sorted leaf
+    uint32_t pj[288];    // depth << 16 | ancestor of every internal node
+    uint32_t icnt[288];  // internal nodes per depth
+    uint32_t num[40];    // leaves per depth (num_codes[33])
     uint8_t ll_len[288];
     uint8_t d_len[32];
     uint8_t cl_len[20];
@@ -1617,27 +1627,130 @@ struct HdrLds {
     uint32_t n_ll, n_d, n_enc, used;
 };
 
+// Moffat-Katajainen phase 1 on one lane: val[0..n) ascending; afterwards val[t] = parent of internal node t
+// for t < n - 2 (length_encode.rs:218-247).  rv / lv = the weights at the heads of the internal-node and the
+// leaf queue; an internal node is made in every round, so its queue is never empty when a round begins.
+__device__ void mk_phase1(uint32_t* val, uint32_t n) {
+    uint32_t root = 0, leaf = 2;
+    uint32_t rv = val[0] + val[1];
+    val[0] = rv;
+    uint32_t lv = leaf < n ? val[leaf] : 0u;
+    for (uint32_t next = 1; next + 1 < n; next++) {
+        uint32_t v;
+        if (leaf >= n || rv < lv) {
+            v = rv;
+            val[root] = next;
+            root++;
+            rv = root < next ? val[root] : 0u;
+        } else {
+            v = lv;
+            leaf++;
+            lv = leaf < n ? val[leaf] : 0u;
+        }
+        if (leaf >= n || (root < next && rv < lv)) {
+            v += rv;
+            val[root] = next;
+            root++;
+            rv = root < next ? val[root] : 0u;
+        } else {
+            v += lv;
+            leaf++;
+            lv = leaf < n ? val[leaf] : 0u;
+        }
+        val[next] = v;
+        if (root == next) rv = v;
+    }
+}
+
 template <class LenArr>
 __device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
                           LenArr& lengths, uint32_t lane) {
     for (uint32_t i = lane; i < n_total; i += 64) lengths[i] = 0;
-    __syncthreads();
-    if (lane == 0) s.m = gather_nodes(freqs, n, s.nodes);
-    __syncthreads();
-    uint32_t m = s.m;
-    if (m >= 2) {
-        for (uint32_t i = lane; i < m; i += 64) {
-            uint32_t key = (s.nodes[i].value << 9) | s.nodes[i].symbol;
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < m; j++) rank += ((s.nodes[j].value << 9) | s.nodes[j].symbol) < key ? 1u : 0u;
-            s.sorted[rank] = s.nodes[i];
+    uint32_t m = 0;  // gather_nodes
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        const uint32_t f = i < n ? freqs[i] : 0u;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(f > 0);
+        if (f > 0) {
+            const uint32_t at = m + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            s.nodes[at].value = f;
+            s.nodes[at].symbol = i;
         }
-    } else if (lane == 0 && m == 1) {
-        s.sorted[0] = s.nodes[0];
+        m += (uint32_t)__popcll(mask);
     }
     __syncthreads();
-    if (lane == 0) lengths_from_sorted(s.sorted, m, max_len, lengths);
+    if (m == 0) return;
+    if (m == 1) {  // length_encode.rs:377-382
+        if (lane == 0) lengths[s.nodes[0].symbol] = 1;
+        __syncthreads();
+        return;
+    }
+    for (uint32_t i = lane; i < m; i += 64) {
+        const uint32_t key = (s.nodes[i].value << 9) | s.nodes[i].symbol;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) rank += ((s.nodes[j].value << 9) | s.nodes[j].symbol) < key ? 1u : 0u;
+        s.val[rank] = s.nodes[i].value;
+        s.sym[rank] = s.nodes[i].symbol;
+    }
     __syncthreads();
+    if (lane == 0) mk_phase1(s.val, m);
+    __syncthreads();
+    // internal nodes 0 .. m-2, the root is m-2: depth = number of parent hops to the root
+    const uint32_t rootn = m - 2;
+    for (uint32_t t = lane; t + 1 < m; t += 64) {
+        s.pj[t] = t < rootn ? (1u << 16) | s.val[t] : rootn;
+        s.icnt[t] = 0;
+    }
+    if (lane < 40) s.num[lane] = 0;
+    __syncthreads();
+    for (uint32_t span = 1; span < m; span <<= 1) {  // after k rounds every word spans 2^k hops or ends at the root
+        uint32_t nw[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const uint32_t t = lane + 64 * k;
+            if (t + 1 < m) {
+                const uint32_t w = s.pj[t], pw = s.pj[w & 0xffff];
+                nw[k] = (((w >> 16) + (pw >> 16)) << 16) | (pw & 0xffff);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const uint32_t t = lane + 64 * k;
+            if (t + 1 < m) s.pj[t] = nw[k];
+        }
+        __syncthreads();
+    }
+    for (uint32_t t = lane; t + 1 < m; t += 64) atomicAdd(&s.icnt[s.pj[t] >> 16], 1u);
+    __syncthreads();
+    if (lane == 0) {
+        // :253-278 level by level: of the `available` slots of a depth the internal nodes take theirs, the
+        // leaves the rest
+        uint32_t available = 1, depth = 0;
+        while (available > 0) {
+            const uint32_t used = depth + 1 < m ? s.icnt[depth] : 0u;
+            if (available > used) s.num[depth < 32 ? depth : 32] += available - used;
+            available = 2 * used;
+            depth++;
+        }
+        limit_code_lengths(s.num, max_len);
+    }
+    __syncthreads();
+    for (uint32_t idx = lane; idx < m; idx += 64) {  // :402-408: the idx-th leaf from the end
+        uint32_t acc = 0, len = 0;
+        for (uint32_t i = 1; i <= max_len; i++) {
+            acc += s.num[i];
+            if (len == 0 && idx < acc) len = i;
+        }
+        lengths[s.sym[m - 1 - idx]] = (uint8_t)len;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
 }
 
 __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
@@ -1655,11 +1768,23 @@ __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const
         for (uint32_t q = 0; q < PSPLIT; q++) f += d_freq[((uint64_t)b * PSPLIT + q) * 32 + lane];
         s.df[lane] = f;
     }
-    if (lane < 19) s.clf[lane] = 0;
+    if (lane < 20) s.clf[lane] = 0;
     __syncthreads();
-    if (lane == 0) {
-        s.n_ll = trimmed_count(s.llf, NUM_LL, 257);
-        s.n_d = trimmed_count(s.df, NUM_DIST, 1);
+    {  // remove_trailing_zeroes huffman_lengths.rs:44-47 (stages.h trimmed_count): the last used symbol
+        uint32_t last_ll = 0, last_d = 0;
+        for (uint32_t i = lane; i < NUM_LL; i += 64)
+            if (s.llf[i]) last_ll = i + 1;
+        if (lane < NUM_DIST && s.df[lane]) last_d = lane + 1;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t a = __shfl_xor(last_ll, off), c = __shfl_xor(last_d, off);
+            last_ll = a > last_ll ? a : last_ll;
+            last_d = c > last_d ? c : last_d;
+        }
+        if (lane == 0) {
+            s.n_ll = last_ll > 257 ? last_ll : 257;
+            s.n_d = last_d > 1 ? last_d : 1;
+        }
     }
     __syncthreads();
     wave_huff(s, s.llf, s.n_ll, 288, 15, s.ll_len, lane);
@@ -1671,26 +1796,48 @@ __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const
     __syncthreads();
     wave_huff(s, s.clf, 19, 19, 7, s.cl_len, lane);
     BlockHeader* h = hdr + b;
-    if (lane == 0) {
-        s.used = count_used_hclens(s.cl_len);
-        uint64_t dyn_bits, dyn_est, static_est, fixed_bits;
-        const uint32_t* pl = s.llf;
-        const uint32_t* pd = s.df;
-        block_costs(pl, pd, s.clf, s.ll_len, s.d_len, s.cl_len, s.n_ll, s.n_d, s.used, &dyn_bits, &dyn_est, &static_est,
-                    &fixed_bits);
-        h->n_enc = s.n_enc;
-        h->n_ll = s.n_ll;
-        h->n_d = s.n_d;
-        h->used_hclens = s.used;
-        h->dyn_bits = dyn_bits;
-        h->dyn_est = dyn_est;
-        h->static_est = static_est;
-        h->fixed_bits = fixed_bits;
+    if (lane == 0) s.used = count_used_hclens(s.cl_len);
+    __syncthreads();
+    {  // stages.h block_costs, summed over the wave
+        uint32_t d_ll = 0, s_ll = 0, d_d = 0, s_d = 0, f_d = 0, table = 0, table_real = 0;
+        for (uint32_t c = lane; c < s.n_ll; c += 64) {
+            const uint32_t f = s.llf[c], extra = c >= 257 ? length_extra_bits_of_code(c - 257) : 0u;
+            d_ll += f * (s.ll_len[c] + extra);
+            s_ll += f * (fixed_ll_length(c) + extra);
+        }
+        if (lane < s.n_d) {
+            const uint32_t f = s.df[lane], extra = distance_extra_bits_of_code(lane);
+            d_d = f * (s.d_len[lane] + extra);
+            s_d = f * (fixed_ll_length(lane) + extra);  // Q12: the ll table is used for distances too
+            f_d = f * (5 + extra);
+        }
+        if (lane < 19) {
+            const uint32_t extra = (lane == 16 || lane == 17) ? 3u : (lane == 18 ? 7u : 0u);
+            const uint32_t extra_real = lane == 16 ? 2u : extra;  // write_huffman_lengths :343 writes 2 bits
+            table = s.clf[lane] * (s.cl_len[lane] + extra);
+            table_real = s.clf[lane] * (s.cl_len[lane] + extra_real);
+        }
+        d_ll = wave_sum(d_ll);
+        s_ll = wave_sum(s_ll);
+        d_d = wave_sum(d_d);
+        s_d = wave_sum(s_d);
+        f_d = wave_sum(f_d);
+        table = wave_sum(table);
+        table_real = wave_sum(table_real);
+        if (lane == 0) {
+            h->n_enc = s.n_enc;
+            h->n_ll = s.n_ll;
+            h->n_d = s.n_d;
+            h->used_hclens = s.used;
+            h->dyn_est = (uint64_t)d_ll + d_d + table + (uint64_t)s.used * 3 + 5 + 5 + 4;
+            h->dyn_bits = (uint64_t)d_ll + d_d + table_real + (uint64_t)s.used * 3 + 5 + 5 + 4;
+            h->static_est = (uint64_t)s_ll + s_d;
+            h->fixed_bits = (uint64_t)s_ll + f_d;
+        }
     }
     for (uint32_t i = lane; i < 288; i += 64) h->ll_len[i] = s.ll_len[i];
     if (lane < 32) h->d_len[lane] = s.d_len[lane];
     if (lane < 19) h->cl_len[lane] = s.cl_len[lane];
-    __syncthreads();
     for (uint32_t i = lane; i < s.n_enc; i += 64) h->enc[i] = s.enc[i];
 }
 

@@ -1165,6 +1165,28 @@ struct HuffNode {
     uint32_t symbol;
 };
 
+// enforce_max_code_lengths length_encode.rs:290-327 on the depth histogram num_codes[0..32] (depths of 32
+// and more counted under 32).
+template <class NumArr>
+MI355_HD void limit_code_lengths(NumArr& num_codes, uint32_t max_len) {
+    uint32_t above = 0;
+    for (uint32_t i = max_len + 1; i < 33; i++) above += num_codes[i];
+    num_codes[max_len] += above;
+    uint32_t total = 0;
+    for (uint32_t i = max_len; i >= 1; i--) total += num_codes[i] << (max_len - i);
+    while (total != (1u << max_len)) {
+        num_codes[max_len]--;
+        for (uint32_t i = max_len - 1; i >= 1; i--) {
+            if (num_codes[i] != 0) {
+                num_codes[i]--;
+                num_codes[i + 1] += 2;
+                break;
+            }
+        }
+        total--;
+    }
+}
+
 // In-place Moffat-Katajainen, the miniz length limiter and the reversed hand-out
 // (length_encode.rs:218-278, 290-327, 392-408).  lengths[] must be zeroed by the caller for
 // all symbols; n >= 2.
@@ -1218,24 +1240,7 @@ MI355_HD void huff_lengths_sorted(NodeArr& leaves, uint32_t n, uint32_t max_len,
     uint32_t num_codes[33];
     for (int i = 0; i < 33; i++) num_codes[i] = 0;
     for (uint32_t i = 0; i < n; i++) num_codes[leaves[i].value < 32 ? leaves[i].value : 32]++;
-    {
-        uint32_t above = 0;
-        for (uint32_t i = max_len + 1; i < 33; i++) above += num_codes[i];
-        num_codes[max_len] += above;
-        uint32_t total = 0;
-        for (uint32_t i = max_len; i >= 1; i--) total += num_codes[i] << (max_len - i);
-        while (total != (1u << max_len)) {
-            num_codes[max_len]--;
-            for (uint32_t i = max_len - 1; i >= 1; i--) {
-                if (num_codes[i] != 0) {
-                    num_codes[i]--;
-                    num_codes[i + 1] += 2;
-                    break;
-                }
-            }
-            total--;
-        }
-    }
+    limit_code_lengths(num_codes, max_len);
     // hand out lengths shortest first, walking the sorted leaves from the end :402-408
     uint32_t li = n;
     for (uint32_t i = 1; i <= max_len; i++)
