@@ -869,6 +869,7 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
     unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     M2_T0
+    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(&s_next, 1u);
@@ -900,6 +901,15 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         swl_start(st, org, start);
         M2_CNT(0, 1)
         M2_T(8)
+#ifndef MI355_M2_STORE_AT_ONCE
+        // The results of the batch before go out here, behind this batch's set-up loads: stores count in
+        // vmcnt like loads, and 64 scattered ones issued at the end of a batch made the next batch's first
+        // load wait for them.
+        if (pend_at != ~0u) {
+            M[E + pend_at] = pend_m;
+            if (HAS_Q) Mq[E + pend_at] = pend_mq;
+        }
+#endif
         for (;;) {
             const uint64_t walk = st.walk;
             if (walk == 0) break;
@@ -911,14 +921,25 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
             swl_service(st, win, org, walk & ~still, (uint64_t)0);
             M2_T(9)
         }
+#ifdef MI355_M2_STORE_AT_ONCE
         if (valid) {
             uint32_t m, mq;
             swl_result(st, &m, &mq);
             M[E + srel] = m;
             if (HAS_Q) Mq[E + srel] = mq;
         }
+#else
+        swl_result(st, &pend_m, &pend_mq);
+        pend_at = valid ? srel : ~0u;
+#endif
         M2_T(13)
     }
+#ifndef MI355_M2_STORE_AT_ONCE
+    if (pend_at != ~0u) {
+        M[E + pend_at] = pend_m;
+        if (HAS_Q) Mq[E + pend_at] = pend_mq;
+    }
+#endif
 #ifdef MI355_MATCH_STATS
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
@@ -1609,16 +1630,19 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
 // Local arrays with a dynamic index would live in scratch memory (one round trip to L2 per access): all
 // tables are in LDS.
 // ---------------------------------------------------------------------------------------------
-struct HdrLds {
-    uint32_t llf[288];
-    uint32_t df[32];
-    uint32_t clf[20];
-    HuffNode nodes[288];
+struct HuffScratch {     // what one wave needs to build one code
+    uint32_t key[288];   // freq << 9 | symbol of the used symbols
     uint32_t val[288];   // sorted frequencies -> Moffat-Katajainen working array
     uint32_t sym[288];   // symbol of every sorted leaf
     uint32_t pj[288];    // depth << 16 | ancestor of every internal node
     uint32_t icnt[288];  // internal nodes per depth
     uint32_t num[40];    // leaves per depth (num_codes[33])
+};
+struct HdrLds {
+    uint32_t llf[288];
+    uint32_t df[32];
+    uint32_t clf[20];
+    HuffScratch w[2];    // wave 0: literal/length code, then the code-length code; wave 1: distance code
     uint8_t ll_len[288];
     uint8_t d_len[32];
     uint8_t cl_len[20];
@@ -1662,39 +1686,61 @@ __device__ void mk_phase1(uint32_t* val, uint32_t n) {
     }
 }
 
+// One code, built by ONE wave (the two waves of the workgroup build the literal/length and the distance
+// code side by side): the lanes hand data to each other through the wave's scratch, so wave_lds_fence
+// stands where a workgroup would need a barrier.
+#ifdef MI355_HDR_TIMERS
+#define HT(i) { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) ht[i] += t_ - ht0; ht0 = __builtin_readcyclecounter(); }
+#define HT_DECL unsigned long long ht0 = __builtin_readcyclecounter();
+__device__ unsigned long long ht[16];
+#else
+#define HT(i)
+#define HT_DECL
+#endif
 template <class LenArr>
-__device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
+__device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
                           LenArr& lengths, uint32_t lane) {
+    HT_DECL
     for (uint32_t i = lane; i < n_total; i += 64) lengths[i] = 0;
     uint32_t m = 0;  // gather_nodes
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
         const uint32_t i = c0 + lane;
         const uint32_t f = i < n ? freqs[i] : 0u;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(f > 0);
-        if (f > 0) {
-            const uint32_t at = m + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-            s.nodes[at].value = f;
-            s.nodes[at].symbol = i;
-        }
+        if (f > 0) s.key[m + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (f << 9) | i;
         m += (uint32_t)__popcll(mask);
     }
-    __syncthreads();
+    wave_lds_fence();
     if (m == 0) return;
     if (m == 1) {  // length_encode.rs:377-382
-        if (lane == 0) lengths[s.nodes[0].symbol] = 1;
-        __syncthreads();
+        if (lane == 0) lengths[s.key[0] & 511u] = 1;
+        wave_lds_fence();
         return;
     }
-    for (uint32_t i = lane; i < m; i += 64) {
-        const uint32_t key = (s.nodes[i].value << 9) | s.nodes[i].symbol;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; j++) rank += ((s.nodes[j].value << 9) | s.nodes[j].symbol) < key ? 1u : 0u;
-        s.val[rank] = s.nodes[i].value;
-        s.sym[rank] = s.nodes[i].symbol;
+    {  // rank sort: a lane's (up to five) keys against every key
+        uint32_t k[5], rank[5];
+#pragma unroll
+        for (uint32_t q = 0; q < 5; q++) {
+            k[q] = lane + 64 * q < m ? s.key[lane + 64 * q] : 0u;
+            rank[q] = 0;
+        }
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t kj = s.key[j];
+#pragma unroll
+            for (uint32_t q = 0; q < 5; q++) rank[q] += kj < k[q] ? 1u : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 5; q++)
+            if (lane + 64 * q < m) {
+                s.val[rank[q]] = k[q] >> 9;
+                s.sym[rank[q]] = k[q] & 511u;
+            }
     }
-    __syncthreads();
+    wave_lds_fence();
+    HT(0)
     if (lane == 0) mk_phase1(s.val, m);
-    __syncthreads();
+    wave_lds_fence();
+    HT(1)
     // internal nodes 0 .. m-2, the root is m-2: depth = number of parent hops to the root
     const uint32_t rootn = m - 2;
     for (uint32_t t = lane; t + 1 < m; t += 64) {
@@ -1702,7 +1748,7 @@ __device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t
         s.icnt[t] = 0;
     }
     if (lane < 40) s.num[lane] = 0;
-    __syncthreads();
+    wave_lds_fence();
     for (uint32_t span = 1; span < m; span <<= 1) {  // after k rounds every word spans 2^k hops or ends at the root
         uint32_t nw[5];
 #pragma unroll
@@ -1713,16 +1759,17 @@ __device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t
                 nw[k] = (((w >> 16) + (pw >> 16)) << 16) | (pw & 0xffff);
             }
         }
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (uint32_t k = 0; k < 5; k++) {
             const uint32_t t = lane + 64 * k;
             if (t + 1 < m) s.pj[t] = nw[k];
         }
-        __syncthreads();
+        wave_lds_fence();
     }
     for (uint32_t t = lane; t + 1 < m; t += 64) atomicAdd(&s.icnt[s.pj[t] >> 16], 1u);
-    __syncthreads();
+    wave_lds_fence();
+    HT(2)
     if (lane == 0) {
         // :253-278 level by level: of the `available` slots of a depth the internal nodes take theirs, the
         // leaves the rest
@@ -1735,7 +1782,8 @@ __device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t
         }
         limit_code_lengths(s.num, max_len);
     }
-    __syncthreads();
+    wave_lds_fence();
+    HT(3)
     for (uint32_t idx = lane; idx < m; idx += 64) {  // :402-408: the idx-th leaf from the end
         uint32_t acc = 0, len = 0;
         for (uint32_t i = 1; i <= max_len; i++) {
@@ -1744,7 +1792,8 @@ __device__ void wave_huff(HdrLds& s, const uint32_t* freqs, uint32_t n, uint32_t
         }
         lengths[s.sym[m - 1 - idx]] = (uint8_t)len;
     }
-    __syncthreads();
+    wave_lds_fence();
+    HT(4)
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -1753,51 +1802,99 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
-                                                     const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr) {
+__global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
+                                                      const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr) {
     __shared__ HdrLds s;
-    uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (b >= sc->nb) return;
-    for (uint32_t i = lane; i < 288; i += 64) {
+    HT_DECL
+    for (uint32_t i = tid; i < 288; i += 128) {
         uint32_t f = i == END_OF_BLOCK ? 1u : 0u;  // output_writer.rs:83
         for (uint32_t q = 0; q < PSPLIT; q++) f += ll_freq[((uint64_t)b * PSPLIT + q) * 288 + i];
         s.llf[i] = f;
     }
-    if (lane < 32) {
+    if (tid < 32) {
         uint32_t f = 0;
-        for (uint32_t q = 0; q < PSPLIT; q++) f += d_freq[((uint64_t)b * PSPLIT + q) * 32 + lane];
-        s.df[lane] = f;
+        for (uint32_t q = 0; q < PSPLIT; q++) f += d_freq[((uint64_t)b * PSPLIT + q) * 32 + tid];
+        s.df[tid] = f;
     }
-    if (lane < 20) s.clf[lane] = 0;
+    if (tid < 20) s.clf[tid] = 0;
     __syncthreads();
-    {  // remove_trailing_zeroes huffman_lengths.rs:44-47 (stages.h trimmed_count): the last used symbol
-        uint32_t last_ll = 0, last_d = 0;
+    if (wv == 0) { HT(5) }
+    if (wv == 0) {
+        // remove_trailing_zeroes huffman_lengths.rs:44-47 (stages.h trimmed_count): the last used symbol
+        uint32_t last_ll = 0;
         for (uint32_t i = lane; i < NUM_LL; i += 64)
             if (s.llf[i]) last_ll = i + 1;
-        if (lane < NUM_DIST && s.df[lane]) last_d = lane + 1;
 #pragma unroll
         for (int off = 32; off; off >>= 1) {
-            const uint32_t a = __shfl_xor(last_ll, off), c = __shfl_xor(last_d, off);
+            const uint32_t a = __shfl_xor(last_ll, off);
             last_ll = a > last_ll ? a : last_ll;
-            last_d = c > last_d ? c : last_d;
         }
-        if (lane == 0) {
-            s.n_ll = last_ll > 257 ? last_ll : 257;
-            s.n_d = last_d > 1 ? last_d : 1;
+        const uint32_t n_ll = last_ll > 257 ? last_ll : 257;
+        if (lane == 0) s.n_ll = n_ll;
+        wave_huff(s.w[0], s.llf, n_ll, 288, 15, s.ll_len, lane);
+    } else {
+        uint32_t last_d = (lane < NUM_DIST && s.df[lane]) ? lane + 1 : 0;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t a = __shfl_xor(last_d, off);
+            last_d = a > last_d ? a : last_d;
         }
+        const uint32_t n_d = last_d > 1 ? last_d : 1;
+        if (lane == 0) s.n_d = n_d;
+        wave_huff(s.w[1], s.df, n_d, 32, 15, s.d_len, lane);
     }
     __syncthreads();
-    wave_huff(s, s.llf, s.n_ll, 288, 15, s.ll_len, lane);
-    wave_huff(s, s.df, s.n_d, 32, 15, s.d_len, lane);
-    for (uint32_t i = lane; i < s.n_ll; i += 64) s.chain[i] = s.ll_len[i];
-    for (uint32_t i = lane; i < s.n_d; i += 64) s.chain[s.n_ll + i] = s.d_len[i];
+    for (uint32_t i = tid; i < s.n_ll; i += 128) s.chain[i] = s.ll_len[i];
+    for (uint32_t i = tid; i < s.n_d; i += 128) s.chain[s.n_ll + i] = s.d_len[i];
     __syncthreads();
-    if (lane == 0) s.n_enc = encode_lengths_rle(s.chain, s.n_ll + s.n_d, s.enc, s.clf);
+    if (wv == 0) { HT(6) }
+    if (wv == 0) {
+        // length_encode.rs:82-155 run by run (stages.h el_run_count / el_run_emit): a lane per run start
+        const uint32_t n_len = s.n_ll + s.n_d;
+        uint64_t starts[5];
+#pragma unroll
+        for (uint32_t q = 0; q < 5; q++) {
+            const uint32_t i = lane + 64 * q;
+            starts[q] = __builtin_amdgcn_ballot_w64(i < n_len && (i == 0 || s.chain[i] != s.chain[i - 1]));
+        }
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 5; q++) {
+            const uint32_t i = lane + 64 * q;
+            const bool st = (starts[q] >> lane) & 1;
+            uint32_t e = n_len;  // where the run ends: the next start, in this chunk or a later one
+#pragma unroll
+            for (uint32_t q2 = 4; q2 > q; q2--)
+                if (starts[q2]) e = 64 * q2 + (uint32_t)__builtin_ctzll(starts[q2]);
+            const uint64_t rest = (starts[q] >> lane) >> 1;
+            if (rest) e = i + 1 + (uint32_t)__builtin_ctzll(rest);
+            const uint32_t v = st ? s.chain[i] : 0u;
+            const uint32_t cnt = st ? el_run_count(v, e - i) : 0u;
+            const uint32_t incl = wave_incl_scan(cnt, lane);
+            if (st) el_run_emit(v, e - i, s.enc, base + incl - cnt);
+            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) s.n_enc = base;
+    }
     __syncthreads();
-    wave_huff(s, s.clf, 19, 19, 7, s.cl_len, lane);
+    for (uint32_t i = tid; i < s.n_enc; i += 128) atomicAdd(&s.clf[el_symbol_index(s.enc[i])], 1u);
+    __syncthreads();
+    if (wv == 0) { HT(7) }
     BlockHeader* h = hdr + b;
-    if (lane == 0) s.used = count_used_hclens(s.cl_len);
+    if (wv == 0) {
+        wave_huff(s.w[0], s.clf, 19, 19, 7, s.cl_len, lane);
+        if (lane == 0) s.used = count_used_hclens(s.cl_len);
+    }
     __syncthreads();
+    if (wv == 1) {
+        for (uint32_t i = lane; i < 288; i += 64) h->ll_len[i] = s.ll_len[i];
+        if (lane < 32) h->d_len[lane] = s.d_len[lane];
+        if (lane < 19) h->cl_len[lane] = s.cl_len[lane];
+        for (uint32_t i = lane; i < s.n_enc; i += 64) h->enc[i] = s.enc[i];
+        return;
+    }
     {  // stages.h block_costs, summed over the wave
         uint32_t d_ll = 0, s_ll = 0, d_d = 0, s_d = 0, f_d = 0, table = 0, table_real = 0;
         for (uint32_t c = lane; c < s.n_ll; c += 64) {
@@ -1835,10 +1932,14 @@ __global__ __launch_bounds__(64) void k_block_header(const DevScalars* sc, const
             h->fixed_bits = (uint64_t)s_ll + f_d;
         }
     }
-    for (uint32_t i = lane; i < 288; i += 64) h->ll_len[i] = s.ll_len[i];
-    if (lane < 32) h->d_len[lane] = s.d_len[lane];
-    if (lane < 19) h->cl_len[lane] = s.cl_len[lane];
-    for (uint32_t i = lane; i < s.n_enc; i += 64) h->enc[i] = s.enc[i];
+    HT(8)
+#ifdef MI355_HDR_TIMERS
+    if (lane == 0 && b == 0) {
+        printf("hdr timers (cycles): load %llu | huff: gather+sort %llu phase1 %llu depths %llu levels+limit %llu handout %llu | (whole first phase %llu) rle %llu rest %llu\n",
+               ht[5], ht[0], ht[1], ht[2], ht[3], ht[4], ht[6], ht[7], ht[8]);
+        for (int i = 0; i < 16; i++) ht[i] = 0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

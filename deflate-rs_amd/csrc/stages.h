@@ -1259,22 +1259,29 @@ MI355_HD uint32_t el_symbol_index(uint32_t e) {
 }
 MI355_HD bool not_max_repetitions(uint32_t l, uint32_t repeats) { return (l == 0 && repeats < 138) || repeats < 6; }
 
-template <class LenArr, class OutArr, class FreqArr>
-MI355_HD uint32_t encode_lengths_rle(const LenArr& lengths, uint32_t n_len, OutArr& out, FreqArr& freqs) {
+// The values pushed by the short-run arm (:135-152 re-reads lengths[skip..]) are known without a read: the
+// run's elements equal `prev`, the one at the current index is `l`.  COUNT = false leaves the symbol
+// frequencies to the caller (the block-header kernel counts them from `out` with the whole wave); the next
+// length is read one round ahead so that a single lane does not wait for it.
+template <bool COUNT, class LenArr, class OutArr, class FreqArr>
+MI355_HD uint32_t encode_lengths_rle_impl(const LenArr& lengths, uint32_t n_len, OutArr& out, FreqArr& freqs) {
     uint32_t n_out = 0;
     uint32_t repeat = 0;
-    uint32_t prev = (~(uint32_t)lengths[0]) & 0xff;
+    uint32_t nextl = lengths[0];
+    uint32_t prev = (~nextl) & 0xff;
     uint32_t idx = 0;
-#define MI355_EL_PUSH(e)                 \
-    do {                                 \
-        uint32_t e__ = (e);              \
-        freqs[el_symbol_index(e__)]++;   \
-        out[n_out++] = (uint16_t)e__;    \
+#define MI355_EL_PUSH(e)                           \
+    do {                                           \
+        uint32_t e__ = (e);                        \
+        if (COUNT) freqs[el_symbol_index(e__)]++;  \
+        out[n_out++] = (uint16_t)e__;              \
     } while (0)
     while (idx < n_len) {
         uint32_t n = idx;
-        uint32_t l = lengths[idx++];
+        uint32_t l = nextl;
+        idx++;
         bool peek_none = idx >= n_len;
+        if (!peek_none) nextl = lengths[idx];
         if (l == prev && not_max_repetitions(l, repeat)) repeat++;
         if (l != prev || peek_none || !not_max_repetitions(l, repeat)) {
             if (repeat >= 3) {
@@ -1294,13 +1301,64 @@ MI355_HD uint32_t encode_lengths_rle(const LenArr& lengths, uint32_t n_len, OutA
                 uint32_t skip = n + extra_skip - repeat;
                 uint32_t extra = (l != 0 || peek_none) ? 1 : 0;
                 uint32_t take = repeat + extra;
-                for (uint32_t k = 0; k < take && skip + k < n_len; k++) MI355_EL_PUSH(lengths[skip + k]);
+                for (uint32_t k = 0; k < take && skip + k < n_len; k++) MI355_EL_PUSH(skip + k < n ? prev : l);
                 repeat = 1 - extra;
             }
         }
         prev = l;
     }
 #undef MI355_EL_PUSH
+    return n_out;
+}
+template <class LenArr, class OutArr, class FreqArr>
+MI355_HD uint32_t encode_lengths_rle(const LenArr& lengths, uint32_t n_len, OutArr& out, FreqArr& freqs) {
+    return encode_lengths_rle_impl<true>(lengths, n_len, out, freqs);
+}
+
+// The same coding run by run -- what the state machine above comes to, and what the block-header kernel does
+// with one lane per run.  A run of c equal lengths v:
+//   v != 0: the first one as itself, the other c - 1 as "copy previous" symbols of 6 (the counter is flushed
+//           when it reaches 6), then the rest r < 6 as one copy symbol if r >= 3, else as r literals;
+//   v == 0: every zero counts (the first one too): zero runs of 138, then the rest r < 138 as symbol 18
+//           (r >= 11), symbol 17 (3..10) or r literal zeros.
+// tests/test_stages_vs_oracle.py holds the two forms against each other.
+MI355_HD uint32_t el_run_count(uint32_t v, uint32_t c) {
+    if (v) {
+        const uint32_t R = c - 1, r = R % 6;
+        return 1 + R / 6 + (r >= 3 ? 1u : r);
+    }
+    const uint32_t r = c % 138;
+    return c / 138 + (r >= 3 ? 1u : r);
+}
+template <class OutArr>
+MI355_HD void el_run_emit(uint32_t v, uint32_t c, OutArr& out, uint32_t at) {
+    if (v) {
+        const uint32_t R = c - 1, r = R % 6;
+        out[at++] = (uint16_t)v;
+        for (uint32_t k = 0; k < R / 6; k++) out[at++] = (uint16_t)((1u << 8) | 6u);
+        if (r >= 3)
+            out[at++] = (uint16_t)((1u << 8) | r);
+        else
+            for (uint32_t k = 0; k < r; k++) out[at++] = (uint16_t)v;
+    } else {
+        const uint32_t r = c % 138;
+        for (uint32_t k = 0; k < c / 138; k++) out[at++] = (uint16_t)((3u << 8) | 138u);
+        if (r >= 3)
+            out[at++] = (uint16_t)(((r <= 10 ? 2u : 3u) << 8) | r);
+        else
+            for (uint32_t k = 0; k < r; k++) out[at++] = (uint16_t)0;
+    }
+}
+template <class LenArr, class OutArr>
+MI355_HD uint32_t encode_lengths_runs(const LenArr& lengths, uint32_t n_len, OutArr& out) {
+    uint32_t n_out = 0;
+    for (uint32_t i = 0; i < n_len;) {
+        uint32_t e = i + 1;
+        while (e < n_len && lengths[e] == lengths[i]) e++;
+        el_run_emit((uint32_t)lengths[i], e - i, out, n_out);
+        n_out += el_run_count((uint32_t)lengths[i], e - i);
+        i = e;
+    }
     return n_out;
 }
 

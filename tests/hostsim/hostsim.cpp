@@ -375,6 +375,19 @@ struct BitSink {
 
 extern "C" {
 
+// encode_lengths_rle (the reference's state machine) against encode_lengths_runs (run by run, what
+// k_block_header does): 0 = same symbols, else 1 + the index of the first difference
+int hostsim_rle_forms_agree(const uint8_t* lens, uint32_t n) {
+    std::vector<uint16_t> a(n + 8), b(n + 8);
+    uint32_t freqs[19] = {0};
+    const uint32_t na = encode_lengths_rle(lens, n, a, freqs);
+    const uint32_t nb = encode_lengths_runs(lens, n, b);
+    if (na != nb) return 1 + (int)std::min(na, nb);
+    for (uint32_t i = 0; i < na; i++)
+        if (a[i] != b[i]) return 1 + (int)i;
+    return 0;
+}
+
 struct hostsim_block {
     uint32_t btype, bfinal, ntok;
     uint64_t in_bytes, bit_start;

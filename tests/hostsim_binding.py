@@ -27,6 +27,8 @@ def lib():
                                      C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]
         L.hostsim_encode.restype = C.c_int
         L.hostsim_match_table.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.hostsim_rle_forms_agree.argtypes = [C.c_char_p, C.c_uint32]
+        L.hostsim_rle_forms_agree.restype = C.c_int
         _lib = L
     return _lib
 
@@ -63,3 +65,8 @@ def match_table(data, checks):
     m = (C.c_uint32 * max(n, 1))()
     lib().hostsim_match_table(bytes(data), n, checks, m)
     return list(m[:n])
+
+
+def rle_forms_agree(lengths: bytes) -> int:
+    """0 if the run-by-run coding of a code-length list equals the reference's state machine"""
+    return lib().hostsim_rle_forms_agree(bytes(lengths), len(lengths))

@@ -199,3 +199,21 @@ def test_identity_hops_never_change_output():
                 agree(data, *LV[level])
     finally:
         hs.force_ident(0)
+
+
+def test_code_length_rle_run_by_run_equals_the_state_machine():
+    """k_block_header codes the chained code lengths run by run (stages.h el_run_count / el_run_emit); the
+    reference's state machine (length_encode.rs:82-155, stages.h encode_lengths_rle, pinned by the KATs of
+    test_oracle_kat.py) must give the same symbols for every list."""
+    import random
+    rnd = random.Random(20260929)
+    cases = [bytes([v]) * c for v in (0, 1, 7, 15) for c in list(range(1, 30)) + [137, 138, 139, 140, 148, 149, 275, 276, 277, 316]]
+    for _ in range(4000):
+        out = bytearray()
+        while len(out) < rnd.choice((1, 5, 19, 60, 287, 316)):
+            v = rnd.choice((0, 0, 0, rnd.randrange(1, 16)))
+            c = rnd.choice((1, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, rnd.randrange(1, 300)))
+            out += bytes([v]) * c
+        cases.append(bytes(out[:316]))
+    for lens in cases:
+        assert hs.rle_forms_agree(lens) == 0, list(lens)
