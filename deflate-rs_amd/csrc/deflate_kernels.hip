@@ -1296,9 +1296,11 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
 // ---------------------------------------------------------------------------------------------
 // k_emit: walk each segment from its entry and write its tokens (output_writer.rs:47-65).
 // ---------------------------------------------------------------------------------------------
-// One wave per segment: lane 0 follows adv[] from the segment's entry (the chain itself is serial,
-// but it now runs on LDS latency), then all lanes expand the path positions into tokens in parallel
-// and a wave scan places them.
+// One wave per segment.  The chain from the segment's entry is serial, so it is made short first: all lanes
+// turn adv[] into two-step and then four-step jumps (in LDS, stopping at the end of the segment), lane 0
+// follows the four-step jumps and records every fourth path position, and every lane then replays the
+// (up to) four steps behind one recorded position -- parse_step gives both the tokens and the way on -- a
+// wave scan places the tokens.
 // (Segments are relative to pos0: the sharded path parses a sub-range [pos0, pos0 + n) of a buffer of
 // n_total bytes; the whole-buffer path has pos0 = 0, n = n_total.)
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
@@ -1314,15 +1316,38 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
     const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
     const uint32_t len = (uint32_t)(b - a);
-    for (uint32_t r = lane; r < len; r += 64) s_adv[wv][r] = adv[(uint64_t)pos0 + a + r];
+    uint16_t* A = s_adv[wv];
+    uint16_t* P = s_pp[wv];
+    for (uint32_t r = lane; r < len; r += 64) A[r] = adv[(uint64_t)pos0 + a + r];
     wave_lds_fence();
+    for (uint32_t r = lane; r < len; r += 64) {  // two steps, or one that leaves the segment
+        const uint32_t t = r + A[r];
+        P[r] = (uint16_t)((t < len ? t + A[t] : t) - r);
+    }
+    wave_lds_fence();
+    // four steps, in place and left to right: an entry reads entries to its right -- those of its own 64 before
+    // any of them is written, those of later ones before their turn
+    for (uint32_t c = 0; c < len; c += 64) {
+        const uint32_t r = c + lane;
+        uint32_t v = 0;
+        if (r < len) {
+            const uint32_t t = r + P[r];
+            v = (t < len ? t + P[t] : t) - r;
+        }
+        wave_lds_fence();
+        if (r < len) P[r] = (uint16_t)v;
+        wave_lds_fence();
+    }
     if (lane == 0) {
+        // the i-th recorded position is at least 4 i: its slot lies at or before the entry just read, and the
+        // chain only reads further right
         uint32_t np = 0;
         uint64_t e = E0[k];
         uint32_t j = e >= b ? len : (uint32_t)(e - a);
         while (j < len) {
-            s_pp[wv][np++] = (uint16_t)j;
-            j += s_adv[wv][j];
+            const uint32_t at = j;
+            j += P[at];
+            P[np++] = (uint16_t)at;
         }
         s_np[wv] = np;
     }
@@ -1330,32 +1355,40 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     const uint32_t np = s_np[wv];
     GM m{M}, mq{Mq ? Mq : M};
     uint32_t* out = tokbuf + a;
+    const uint64_t jend = (uint64_t)pos0 + b;
     uint32_t running = 0;
     for (uint32_t i0 = 0; i0 < np; i0 += 64) {
-        uint32_t idx = i0 + lane;
-        bool have = idx < np;
-        Step st;
-        st.nlit = 0;
-        st.mlen = 0;
-        st.mdist = 0;
-        st.adv = 0;
-        uint64_t j = 0;
-        if (have) {
-            j = (uint64_t)pos0 + a + s_pp[wv][idx];
-            st = parse_step(m, mq, j, (uint64_t)seg_end(sg, j), cfg);
+        const uint32_t idx = i0 + lane;
+        const bool have = idx < np;
+        uint32_t nl[4], tm[4], ntok = 0;
+        uint64_t jp[4];
+        uint64_t j = have ? (uint64_t)pos0 + a + P[idx] : jend;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            nl[q] = 0;
+            tm[q] = 0;
+            jp[q] = j;
+            if (j < jend) {
+                const Step st = parse_step(m, mq, j, (uint64_t)seg_end(sg, j), cfg);
+                nl[q] = st.nlit;
+                tm[q] = st.mlen ? tok_match(st.mlen, st.mdist) : 0u;  // (never 0 for a match: dist >= 1)
+                ntok += st.nlit + (st.mlen ? 1u : 0u);
+                j += st.adv;
+            }
         }
-        uint32_t ntok = st.nlit + (st.mlen ? 1u : 0u);
         uint32_t incl = ntok;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             uint32_t v = __shfl_up(incl, off);
             if (lane >= (uint32_t)off) incl += v;
         }
-        uint32_t total = __shfl(incl, 63);
-        if (have) {
-            uint32_t* o = out + running + (incl - ntok);
-            for (uint32_t q = 0; q < st.nlit; q++) o[q] = tok_literal(in[j + q]);
-            if (st.mlen) o[st.nlit] = tok_match(st.mlen, st.mdist);
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t* o = out + running + (incl - ntok);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            for (uint32_t x = 0; x < nl[q]; x++) o[x] = tok_literal(in[jp[q] + x]);
+            o += nl[q];
+            if (tm[q]) *o++ = tm[q];
         }
         running += total;
     }
