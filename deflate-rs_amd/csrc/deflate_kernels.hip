@@ -2008,7 +2008,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         // Only the cost of a Stored block (and the pad of a sync marker) depends on the bit phase a block
         // starts at.  A block whose type and length come out the same for all eight phases needs no
         // walk: when that holds for all 64 blocks of the group, their bit offsets are a prefix sum.
-        bool fixed_len = have && my_sync == 0;
+        bool fixed_len = have && my_sync == 0, fixed_type = fixed_len;
         BlockPlan p0;
         p0.btype = BT_FIXED;
         p0.bfinal = 0;
@@ -2020,8 +2020,34 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             for (uint32_t ph = 1; ph < 8; ph++) {
                 BlockPlan q;
                 plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, false, ph, &q);
+                fixed_type = fixed_type && q.btype == p0.btype;
                 fixed_len = fixed_len && q.btype == p0.btype && q.bit_len == p0.bit_len;
             }
+        }
+        // A group of blocks that are Stored whatever the phase (incompressible data): a stored block ends on a
+        // byte boundary, so every block but the group's first starts at phase 0 -- the length p0 was computed
+        // for -- and the first one takes the real phase.
+        if (__builtin_amdgcn_ballot_w64(have && !(fixed_type && p0.btype == BT_STORED)) == 0) {
+            if (lane == 0) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb, bitpos, &p0);
+            const uint64_t mylen = have ? p0.bit_len : 0ull;
+            uint64_t incl = mylen;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t ylo = __shfl_up((uint32_t)incl, off), yhi = __shfl_up((uint32_t)(incl >> 32), off);
+                if (lane >= (uint32_t)off) incl += ((uint64_t)yhi << 32) | ylo;
+            }
+            if (have) {
+                p0.bit_start = bitpos + (incl - mylen);
+                plan[b] = p0;
+                n_st++;
+                if (my_q13) {
+                    hits++;
+                    if (my_q13 == 2 && (compat & 1)) panic = 1;
+                }
+            }
+            bitpos += ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63) << 32) |
+                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
+            continue;
         }
         if (__builtin_amdgcn_ballot_w64(have && !fixed_len) == 0) {
             const uint32_t mylen = have ? (uint32_t)p0.bit_len : 0u;  // < 2^21 for a non-stored block
