@@ -262,7 +262,7 @@ def main():
         traffic = None
         lds_conflict = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")))
             if pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1:
                 traffic = pm["kernels"][dominant]["hbm_bytes"]
                 lds_conflict = pm["kernels"][dominant].get("lds_bank_conflict_rate")
