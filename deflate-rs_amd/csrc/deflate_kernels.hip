@@ -7,7 +7,7 @@
 //   M, Mq  u32[n]      longest_match(prev_length = 0) at full / quarter budget   4 (+4) B/byte
 //   adv    u16[n]      restart step length from every position                   2 B/byte
 //   J      u16[n]      scratch of the per-segment exit sweep                     2 B/byte
-//   X[l]   u32[K_l*ZONE]  exit tables per level, E[l] u32[K_l] entry positions
+//   X[l]   u16[K_l*ZONE]  exit tables per level (an exit lies less than MAX_JUMP beyond its unit), E[l] u32[K_l] entry positions
 //   tokbuf u32[K*SEG]  tokens per segment, dtok u32[T] tokens in stream order    4 + 4 B/byte
 //   per block: ll_freq u32[288], d_freq u32[32], BlockHeader, BlockPlan, bstart
 // All integer work; the bound is LDS/issue rate in k_match and HBM elsewhere.
@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
 // is resolved at once (from the table of the chunks already done, kept in LDS); jumps that stay
 // inside the chunk are resolved by pointer jumping across lanes (<= 7 rounds).
 __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
-                                                  uint32_t* __restrict__ X0) {
+                                                  uint16_t* __restrict__ X0) {
     __shared__ uint16_t sJ[4][SEG];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
@@ -1252,14 +1252,14 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
         if (valid) J[r] = (uint16_t)val;
         wave_lds_fence();
     }
-    uint32_t* x = X0 + k * ZONE;
-    for (uint32_t e = lane; e < ZONE; e += 64) x[e] = e < len ? (uint32_t)J[e] : e - len;
+    uint16_t* x = X0 + k * ZONE;
+    for (uint32_t e = lane; e < ZONE; e += 64) x[e] = e < len ? J[e] : (uint16_t)(e - len);
 }
 
 // k_level_up: compose FAN child tables into one parent table.
 __global__ __launch_bounds__(256) void k_level_up(uint32_t n, uint32_t nc, uint64_t csize,
-                                                  const uint32_t* __restrict__ C, uint32_t nu,
-                                                  uint32_t* __restrict__ X) {
+                                                  const uint16_t* __restrict__ C, uint32_t nu,
+                                                  uint16_t* __restrict__ X) {
     uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (uint64_t)nu * ZONE) return;
     uint64_t u = gid / ZONE;
@@ -1274,12 +1274,12 @@ __global__ __launch_bounds__(256) void k_level_up(uint32_t n, uint32_t nc, uint6
         uint64_t cend = cstart + csize < n ? cstart + csize : n;
         if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
     }
-    X[gid] = (uint32_t)(pos - uend);
+    X[gid] = (uint16_t)(pos - uend);
 }
 
 // k_level_down: given the entry position of every parent unit, the entry of each child.
 __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint64_t csize,
-                                                   const uint32_t* __restrict__ C, uint32_t nu,
+                                                   const uint16_t* __restrict__ C, uint32_t nu,
                                                    const uint32_t* __restrict__ Eparent, uint32_t* __restrict__ Echild) {
     uint64_t u = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (u >= nu) return;
