@@ -106,6 +106,23 @@ def test_random_block_fill_q1_q8(da, ctx):
     assert hit_q1 > 0  # the hash re-warm quirk (lz77.rs:628-638) must have fired and been reproduced
 
 
+def test_block_part_boundaries(da, ctx):
+    """k_block_hist / k_pack cut a block's tokens into four parts of 7 936 (a part's first bit comes from the
+    histograms of the parts before it): last blocks whose token count sits on, just before and just behind
+    every part boundary.  huffman_only = one literal token per byte, so the byte count sets the token count."""
+    pq = 31744 // 4
+    base = datagen.text_like(31744 + 4 * pq + 8, 99)
+    for k in range(0, 5):
+        for d in (-1, 0, 1):
+            n = 31744 + k * pq + d
+            if n <= 0:
+                continue
+            agree(da, ctx, base[:n], *LV["huffman_only"])
+            agree(da, ctx, datagen.rng_bytes(n, n), *LV["huffman_only"])
+    for n in (1, pq - 1, pq, pq + 1, 2 * pq, 3 * pq + 1):
+        agree(da, ctx, base[:n], *LV["huffman_only"])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_mixed_inputs(da, ctx, seed):
     data = datagen.mixed([50000, 140000, 300000, 1000000, 70000, 2000000][seed], seed)
