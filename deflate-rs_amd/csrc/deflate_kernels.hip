@@ -17,6 +17,7 @@
 #ifdef MI355_MATCH_STATS
 // instrumented build (tools/variants.sh): per-lane counters of match_walk_park, summed over the launch
 __device__ unsigned long long g_mstats[16];
+__device__ unsigned long long g_sstats[16];  // k_sort's phase clocks (KS_T)
 #define MI355_STAT_DECL uint32_t stat_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MI355_STAT(i, v) stat_[i] += (v);
 #define MI355_STAT_FLUSH(policy)                                                          \
@@ -493,7 +494,7 @@ __device__ __forceinline__ void wave_match(uint32_t d, bool valid, uint32_t* plo
 #define KS_T(i)                                                                        \
     if (threadIdx.x == 0) {                                                            \
         unsigned long long t_ = __builtin_readcyclecounter();                          \
-        atomicAdd(&g_mstats[i], t_ - ks_t);                                            \
+        atomicAdd(&g_sstats[i], t_ - ks_t);                                            \
         ks_t = t_;                                                                     \
     }
 #else

@@ -5,10 +5,10 @@ os.environ["MI355_DEFLATE_LIB"] = os.path.join(ROOT, "deflate-rs_amd", "variants
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datagen, deflate_amd as da
 n = 20_000_000
-data = datagen.text_like(n, 0x656E)
+data = bytes(n) if len(sys.argv) > 1 and sys.argv[1] == "zeros" else datagen.text_like(n, 0x656E)
 ctx = da.Context(0); L = da.load(); out = (C.c_ulonglong * 16)()
-ctx.encode(data, da.Compression.Fast); L.mi355_debug_match_stats(out, 1)
-ctx.encode(data, da.Compression.Fast); L.mi355_debug_match_stats(out, 1)
+ctx.encode(data, da.Compression.Default); L.mi355_debug_sort_stats(out, 1)
+ctx.encode(data, da.Compression.Default); L.mi355_debug_sort_stats(out, 1)
 s = list(out)[:8]
 names = ["hash+hist", "bucket starts", "p1 count", "p1 offsets", "p1 scatter", "p2 count", "p2 offsets", "p2 scatter"]
 tot = sum(s); ne = (n + 32767) // 32768
