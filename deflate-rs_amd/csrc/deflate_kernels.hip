@@ -515,18 +515,32 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
     // the digits of the wave's keys stay in registers (four per register) between the count and the scatter:
     // the second pass reads them through an indirection it then does not have to repeat
     uint32_t dc[NBAT / 4];
+    // ... and so do a key's rank among the wave's keys of the same digit and whether it is their last (four
+    // keys per register): the lanes of a digit are found once, here, and the digit's first lane counts for all of them
+    // -- 64 atomics on one counter (a hot digit; a run of one byte) would be served one after the other
+    uint32_t bt[NBAT / 4];
+    uint32_t Jc = J;
+    asm volatile("" : "+s"(Jc));  // (a copy the compiler cannot match with the other pass's: it kept all 32 `i < J` of a pass alive as 0/1 registers, spilling them)
 #pragma unroll
     for (int b = 0; b < NBAT; b++) {
         const uint32_t i = cb + 64 * b + lane;
-        uint32_t d = 0;
-        if (i < J) {
-            d = dig(i);
-            atomicAdd(&mine[d], 1u);
-        }
+        const bool valid = i < Jc;
+        const uint32_t d = valid ? dig(i) : 0u;
+        uint32_t plo, phi;
+        wave_match<NB>(d, valid, &plo, &phi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t total = (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi);
+        if (valid && below == 0) atomicAdd(&mine[d], total);
         if ((b & 3) == 0)
             dc[b >> 2] = d;
         else
             dc[b >> 2] |= d << (8 * (b & 3));
+        const uint32_t pk = below | (below + 1 == total ? 64u : 0u) | (valid ? 128u : 0u);  // below < 64
+        if ((b & 3) == 0)
+            bt[b >> 2] = pk;
+        else
+            bt[b >> 2] |= pk << (8 * (b & 3));
+        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the 32 batches' digits from being fetched all at once)
     }
     __syncthreads();
     KS_T(stat0)
@@ -553,19 +567,17 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
 #pragma unroll
     for (int b = 0; b < NBAT; b++) {
         const uint32_t i = cb + 64 * b + lane;
-        const bool valid = i < J;
         const uint32_t d = (dc[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const uint32_t pk = (bt[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const bool valid = (pk & 128u) != 0;  // (not `i < J` again: the compiler would keep 32 of those alive from the count)
         const uint32_t py = valid ? pay(i) : 0u;
-        uint32_t plo, phi;
-        wave_match<NB>(d, valid, &plo, &phi);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-        const uint32_t total = (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi);
+        const uint32_t below = pk & 63u;
         uint32_t at = 0;
         if (valid) at = mine[d];
         wave_lds_fence();  // every lane has read its offset before the last lane of each digit moves it on
         if (valid) {
             put(at + below, py);
-            if (below + 1 == total) mine[d] = at + total;
+            if (pk & 64u) mine[d] = at + below + 1;  // the digit's last lane moves the offset on
         }
         wave_lds_fence();
     }
