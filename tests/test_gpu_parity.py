@@ -123,6 +123,18 @@ def test_block_part_boundaries(da, ctx):
         agree(da, ctx, base[:n], *LV["huffman_only"])
 
 
+def test_large_host_input_goes_over_in_pieces(da, ctx):
+    """mi355_deflate_encode copies a host input of 16 MiB or more in eight pieces and starts sorting / walking
+    the first epochs while the rest is on the bus (deflate_host.inc encode_host, launch_match_tables): same
+    bytes as the oracle, for the sizes around a piece boundary, raw and zlib, and for a level on the other paths."""
+    base = datagen.text_like(21_000_000, 123)
+    for n in (16 << 20, (16 << 20) + 1, 20_000_003, 21_000_000):
+        agree(da, ctx, base[:n], *LV["default"])
+    assert da.deflate_bytes_zlib(base[:17_000_000], ctx) == ob.encode(base[:17_000_000], level=ob.DEFAULT, wrapper=1)
+    agree(da, ctx, base[:17_000_000], *LV["fast"])
+    agree(da, ctx, datagen.rng_bytes(17_000_000, 5), *LV["default"])  # Q1 fires: second pass over the head
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_mixed_inputs(da, ctx, seed):
     data = datagen.mixed([50000, 140000, 300000, 1000000, 70000, 2000000][seed], seed)
