@@ -100,7 +100,9 @@ void mi355_deflate_ctx_destroy(mi355_deflate_ctx* ctx);
 const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
- * in, host buffer out.  ctx may be NULL (the default context, see above). */
+ * in, host buffer out.  ctx may be NULL (the default context, see above).  An input of 16 MiB or more is
+ * copied in two pieces and worked on while the second is still on the bus; that only overlaps when `in` is
+ * page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap. */
 int mi355_deflate_encode(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
                          uint8_t* out, size_t out_cap, size_t* out_len);
 
