@@ -162,7 +162,9 @@ constexpr int LG = MI355_LINKS_LG;
 // With true hashes such a candidate (and everything behind it) differs within the first three
 // bytes and cannot change a result, so it is left out; after a hash re-warm (HashOverride) two
 // positions are filed under hashes unrelated to their bytes, these hops become real candidates,
-// and the first two epochs reproduce them.
+// and the first two epochs reproduce them.  ident == 2: in every epoch (the table goes back to head[h] = h for
+// every bucket whose last entry slides out, chained_hash_table.rs:197-219) -- for the positions that a one-byte
+// write after a flush files a byte late (HashOverride::skw), wherever they are in the stream.
 __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict__ link,
                                                 const uint16_t* __restrict__ hl, uint32_t ident) {
     __shared__ uint16_t head[32768];
@@ -170,8 +172,9 @@ __global__ __launch_bounds__(64) void k_links_b(uint32_t n, uint16_t* __restrict
     const uint32_t c0 = blockIdx.x * (uint32_t)WINDOW_SIZE;
     const uint32_t start = c0 >= (uint32_t)WINDOW_SIZE ? c0 - WINDOW_SIZE : 0;
     const uint32_t bias = c0 >= (uint32_t)WINDOW_SIZE ? 0 : WINDOW_SIZE;  // table value of position p: p - start + bias
-    const bool id = ident && blockIdx.x < 2;
-    for (uint32_t i = lane; i < 32768; i += 64) head[i] = id ? (uint16_t)(i - start + bias) : (uint16_t)0xFFFF;
+    const bool id = ident == 2 || (ident && blockIdx.x < 2);
+    // (identity: bucket h points at the position h bytes into the buffer, i.e. start + h: table value h + bias)
+    for (uint32_t i = lane; i < 32768; i += 64) head[i] = id ? (uint16_t)(i + bias) : (uint16_t)0xFFFF;
     __syncthreads();
     const uint32_t stop = c0 + WINDOW_SIZE < n ? c0 + WINDOW_SIZE : n;
     // One wave, nothing else on its SIMD: every instruction counts.  Both arrays are padded by

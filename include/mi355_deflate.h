@@ -241,8 +241,9 @@ int mi355_deflate_stream_new(mi355_deflate_ctx* ctx, const mi355_deflate_opts* o
 int mi355_deflate_stream_write(mi355_deflate_stream* s, const uint8_t* data, size_t n);
 /* io::Write::flush (Flush::Sync, src/writer.rs:134-137, 274-277; src/compress.rs:256-261; src/lz77.rs:
  * 605-614, 728-740): what was written so far is emitted in non-final blocks + 00 00 FF FF, the window
- * is kept.  Two write patterns whose hash-table side effects are not reproduced make finish() return
- * MI355_E_UNSUPPORTED: a flush after only 1-2 bytes, and a 1-byte write right after a flush. */
+ * is kept.  The hash-table side effects the reference has for writes of one or two bytes around a flush
+ * (positions filed late, under a stale rolling hash, or not at all; the re-warm of the first window) are
+ * reproduced for every pattern; no write / flush sequence is refused. */
 int mi355_deflate_stream_flush(mi355_deflate_stream* s);
 int mi355_deflate_stream_finish(mi355_deflate_stream* s);
 /* GzEncoder::from_builder (src/writer.rs:346-358): header bytes of a wrapper-2 stream, before the first

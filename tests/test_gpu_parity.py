@@ -717,7 +717,61 @@ def test_issue_26_and_the_write_patterns_around_a_flush(da, ctx):
                 got = enc.finish().getvalue()
                 assert got == ref.finish(), (lv, [x if x == "F" else len(x) for x in script], wrapper)
                 assert (zlib.decompress(got) if wrapper else inflate_raw(got)) == whole
-    assert refused == 3 * 2 * 4  # the four scripts with such a pair of flushes, at every level and wrapper
+    assert refused == 0  # (round 1 refused two flushes one or two bytes apart)
+
+
+def test_tiny_flush_gaps(da, ctx):
+    """Writes of 1-4 bytes between sync flushes -- at the start of a stream, inside and beyond the first window,
+    around the window edge -- against the oracle: the reference re-adds, skips and re-warms hash entries in
+    these calls (lz77.rs:601-638), and nothing of it may be refused or come out differently
+    (a slice of tools/fuzz_flush_gaps.py; round 1 refused two flushes one or two bytes apart)."""
+    import io
+    import random
+    n = 140000
+    for seed in list(range(1, 90)) + [289, 342, 2133]:
+        rnd = random.Random(seed)
+        kind = rnd.choice(["per", "text", "zeros", "rng"])
+        data = {"per": (datagen.rng_bytes(rnd.choice([1, 3, 300, 4099]), seed) * n)[:n], "text": datagen.text_like(n, seed),
+                "zeros": bytes(n), "rng": datagen.rng_bytes(n, seed)}[kind]
+        pre = rnd.choice([0, 1, 2, 3, 4, 100, 5000, 30000, 32765, 32766, 32767, 32768, 32769, 32770, 40000, 65535, 65536,
+                          65537, 70000])
+        ops, pos = ([pre] if pre else []), pre
+        for _ in range(rnd.randrange(1, 9)):
+            if rnd.random() < 0.45:
+                ops.append("F")
+            else:
+                k = rnd.choice([1, 1, 1, 2, 2, 3, 4, rnd.randrange(1, 2000)])
+                ops.append(k)
+                pos += k
+        tail = rnd.choice([0, 1, 2, 50, 3000, 70000])
+        if tail:
+            ops.append(min(tail, n - pos))
+        lv = rnd.choice(["fast", "default", "best", "rle"])
+        c, l, m = LV[lv]
+        wrapper = rnd.choice([0, 1])
+        enc = (da.ZlibEncoder if wrapper else da.DeflateEncoder)(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+        ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+        p = 0
+        for op in ops:
+            if op == "F":
+                enc.flush()
+                ref.flush()
+            else:
+                enc.write_all(data[p:p + op])
+                ref.write_all(data[p:p + op])
+                p += op
+        assert enc.finish().getvalue() == ref.finish(), (seed, kind, lv, wrapper, ops)
+    # the pattern that showed the identity entries of later epochs: a one-byte write after a flush, period-3 data
+    per3 = (datagen.rng_bytes(3, 1) * n)[:n]
+    for F in (40000, 65535, 65536, 70000, 100000):
+        enc = da.DeflateEncoder(io.BytesIO(), da.CompressionOptions(*LV["fast"]), ctx)
+        ref = ob.Stream(ob.make_opts(*LV["fast"], 0))
+        for e in (enc, ref):
+            e.write_all(per3[:F])
+            e.flush()
+            e.write_all(per3[F:F + 1])
+            e.write_all(per3[F + 1:])
+        assert enc.finish().getvalue() == ref.finish(), F
 
 
 # ---- SURVEY section 8 f4: gzip wrapper, CRC-32 on the GPU (feature "gzip": lib.rs:242-286, writer.rs:293-467) ----
