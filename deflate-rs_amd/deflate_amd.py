@@ -138,6 +138,8 @@ def load():
     L.mi355_shard_emit.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
     L.mi355_shard_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(BlockCost), C.c_size_t]
+    L.mi355_shard_blocks_ex.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64),
+                                        C.POINTER(BlockCost), C.c_size_t]
     L.mi355_plan_blocks.argtypes = [C.POINTER(BlockCost), C.c_size_t, C.c_uint32, C.POINTER(BlockInfo),
                                     C.POINTER(C.c_uint64)]
     L.mi355_shard_pack.argtypes = [C.c_void_p, C.POINTER(BlockInfo), C.c_uint64, C.c_void_p, C.c_size_t,
@@ -182,7 +184,8 @@ EXPORTED = [
     "mi355_deflate_ctx_reserve", "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset",
     "mi355_deflate_encode_gzip",
     "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
-    "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_plan_blocks",
+    "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_shard_blocks_ex",
+    "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
 ]
 
@@ -549,33 +552,28 @@ class Shard:
             self.ctx._err(rc)
         return n.value, (p.value or 0)
 
-    def blocks(self, skip, d_tail_ptr, n_tail):
-        """-> list of cost tuples (dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, q13)"""
-        nb = C.c_uint64(0)
-        cap = 1 << 16
-        costs = (BlockCost * cap)()
-        rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, cap)
-        if rc != OK:
-            self.ctx._err(rc)
-        if nb.value > cap:
-            costs = (BlockCost * nb.value)()
-            rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, nb.value)
-            if rc != OK:
-                self.ctx._err(rc)
-        self.nb = nb.value
-        return [(c.dyn_bits, c.dyn_est, c.static_est, c.fixed_bits, c.in_bytes, c.q13) for c in costs[: nb.value]]
+    def _blocks_call(self, skip, d_tail_ptr, n_tail, owns_final, nb, costs, cap):
+        if owns_final is None:  # "the last rank owns the last block" (every range reaches its next block boundary)
+            return load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, cap)
+        return load().mi355_shard_blocks_ex(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, 1 if owns_final else 0,
+                                            C.byref(nb), costs, cap)
 
-    def blocks_raw(self, skip, d_tail_ptr, n_tail):
+    def blocks(self, skip, d_tail_ptr, n_tail, owns_final=None):
+        """-> list of cost tuples (dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, q13)"""
+        n, costs = self.blocks_raw(skip, d_tail_ptr, n_tail, owns_final)
+        return [(c.dyn_bits, c.dyn_est, c.static_est, c.fixed_bits, c.in_bytes, c.q13) for c in costs[:n]]
+
+    def blocks_raw(self, skip, d_tail_ptr, n_tail, owns_final=None):
         """-> (number of blocks, ctypes array of BlockCost): no per-block Python work (the distributed driver)"""
         nb = C.c_uint64(0)
         cap = 1 << 14
         costs = (BlockCost * cap)()
-        rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, cap)
+        rc = self._blocks_call(skip, d_tail_ptr, n_tail, owns_final, nb, costs, cap)
         if rc != OK:
             self.ctx._err(rc)
         if nb.value > cap:
             costs = (BlockCost * nb.value)()
-            rc = load().mi355_shard_blocks(self._h, skip, C.c_void_p(d_tail_ptr), n_tail, C.byref(nb), costs, nb.value)
+            rc = self._blocks_call(skip, d_tail_ptr, n_tail, owns_final, nb, costs, nb.value)
             if rc != OK:
                 self.ctx._err(rc)
         self.nb = nb.value

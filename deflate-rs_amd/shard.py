@@ -96,18 +96,49 @@ def p1_entries(layouts, tables):
 
 
 def p1_token_split(counts):
-    """From the token counts: for every rank (skip, tail) = how many of its first tokens belong to the
-    left neighbour's last block, and how many tokens it needs from the right neighbour."""
-    world = len(counts)
-    first = [0] * world
-    for r in range(1, world):
-        first[r] = first[r - 1] + counts[r - 1]
-    skip = [(-first[r]) % BLOCK_TOKENS if r else 0 for r in range(world)]
-    for r in range(world):
-        if skip[r] > counts[r]:
-            raise ValueError("rank %d holds fewer tokens than one block boundary needs; use fewer ranks" % r)
-    tail = [skip[r + 1] if r + 1 < world else 0 for r in range(world)]
+    """From the token counts: for every rank (skip, tail) = how many of its first tokens belong to a block that
+    began to its left, and how many tokens it needs from its right to complete its last block.
+    (The form for ranges that all reach their next block boundary; p1_token_plan is the general one.)"""
+    skip, tail, _, _ = p1_token_plan(counts)
     return skip, tail
+
+
+def p1_token_plan(counts):
+    """Blocks are every 31 744 tokens of the one global sequence; a block belongs to the rank that holds its first
+    token.  -> (skip, tail, owns_final, pieces): per rank the tokens at its start that belong to a block begun
+    further left (all of them, if its range does not reach the next boundary: it then owns no block), the
+    tokens it needs behind its own to complete its last block, whether it owns the stream's last block, and
+    where the tail comes from: [(rank, n), ...] = the first n tokens of the ranks to its right, in order."""
+    world = len(counts)
+    first = [0] * (world + 1)
+    for r in range(world):
+        first[r + 1] = first[r] + counts[r]
+    T = first[world]
+    final_first = T // BLOCK_TOKENS * BLOCK_TOKENS  # first token of the last block (== T: an empty last block)
+    skip, tail, owns, pieces = [], [], [], []
+    for r in range(world):
+        lo, hi = first[r], first[r + 1]
+        sk = min(counts[r], (-lo) % BLOCK_TOKENS) if r else 0
+        own_lo = lo + sk                      # first token of the first block it owns, if own_lo < hi
+        # (an empty last block begins "at" T: it goes to the last rank, which owns it even with no token of its own)
+        of = (lo <= final_first < hi) if final_first < T else (r == world - 1)
+        t = 0
+        if own_lo < hi:                       # it owns at least one block
+            last_first = (hi - 1) // BLOCK_TOKENS * BLOCK_TOKENS
+            end = min(last_first + BLOCK_TOKENS, T)
+            t = max(0, end - hi)
+        pc, need, q = [], t, r + 1
+        while need > 0:
+            k = min(need, counts[q])
+            if k:
+                pc.append((q, k))
+            need -= k
+            q += 1
+        skip.append(sk)
+        tail.append(t)
+        owns.append(bool(of))
+        pieces.append(pc)
+    return skip, tail, owns, pieces
 
 
 def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
@@ -131,11 +162,22 @@ def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
     entries = p1_entries(lay, tables)
     toks = [shards[r].emit(entries[r] - lay[r]["g_lo"]) for r in range(world)]  # (count, dptr)
     counts = [c for c, _ in toks]                                              # exchange 2
-    skip, tail = p1_token_split(counts)
+    skip, tail, owns, pieces = p1_token_plan(counts)
     costs = []
+    keep = []
     for r in range(world):                                                     # exchange 3: straddling tokens
-        tail_ptr = toks[r + 1][1] if tail[r] else 0
-        costs.append(shards[r].blocks(skip[r], tail_ptr, tail[r]))
+        tail_ptr = 0
+        if len(pieces[r]) == 1:
+            tail_ptr = toks[pieces[r][0][0]][1]
+        elif pieces[r]:  # the block runs over several ranks to the right: their heads, one after the other
+            t = torch.empty(tail[r], dtype=torch.int32, device=bufs[r].device)
+            off = 0
+            for q, k in pieces[r]:
+                ctypes_copy_d2d(t.data_ptr() + 4 * off, toks[q][1], 4 * k)
+                off += k
+            keep.append(t)
+            tail_ptr = t.data_ptr()
+        costs.append(shards[r].blocks(skip[r], tail_ptr, tail[r], owns[r]))
     allc = [c for cs in costs for c in cs]                                     # exchange 4
     plans, total_bits = da.plan_blocks(allc, compat)
     out = torch.zeros((total_bits + 7) // 8 + 16, dtype=torch.uint8)
@@ -205,28 +247,22 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     mark("x1 exit tables")
     n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
     mark("emit")
-    # round 2: token counts; meanwhile the head of every rank's tokens is on its way to the left neighbour,
-    # which may need up to 31 743 of them to complete its last block (how many is known only with the counts)
-    head_n = min(n_tok, BLOCK_TOKENS - 1) if rank > 0 else 0
-    ops = []
-    if rank > 0:
-        head = torch.zeros(BLOCK_TOKENS - 1, dtype=torch.int32, device=dev)
-        if head_n:
-            ctypes_copy_d2d(head.data_ptr(), tok_ptr, head_n * 4)
-        ops.append(dist.P2POp(dist.isend, head.to(cdev), rank - 1, group))
-    tail_c = None
-    if rank + 1 < world:
-        tail_c = torch.empty(BLOCK_TOKENS - 1, dtype=torch.int32, device=cdev)
-        ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1, group))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
-    cnt = torch.tensor([n_tok], dtype=torch.int64, device=cdev)
-    allc_t = torch.empty(world, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(allc_t, cnt, group=group)
-    counts = allc_t.tolist()
-    skip, tail = p1_token_split(counts)
-    for q in reqs:
-        q.wait()
-    tail_t = tail_c[: tail[rank]].to(dev) if (tail_c is not None and tail[rank]) else None
+    # round 2: token counts and the head of every rank's tokens (a rank may need up to 31 743 tokens from its right
+    # to complete its last block -- from the next rank, or from several when their ranges are short): one gather
+    head_n = min(n_tok, BLOCK_TOKENS - 1)
+    rec2 = torch.zeros(BLOCK_TOKENS + 1, dtype=torch.int32, device=dev)
+    if head_n:
+        ctypes_copy_d2d(rec2.data_ptr() + 8, tok_ptr, head_n * 4)
+    rec2[:2] = torch.tensor([n_tok & 0x7FFFFFFF, n_tok >> 31], dtype=torch.int32)
+    all2 = torch.empty(world * (BLOCK_TOKENS + 1), dtype=torch.int32, device=cdev)
+    dist.all_gather_into_tensor(all2, rec2.to(cdev), group=group)
+    all2 = all2.view(world, BLOCK_TOKENS + 1)
+    cnts = all2[:, :2].tolist()
+    counts = [int(a) | (int(b) << 31) for a, b in cnts]
+    skip, tail, owns, pieces = p1_token_plan(counts)
+    tail_t = None
+    if tail[rank]:
+        tail_t = torch.cat([all2[q, 2:2 + k] for q, k in pieces[rank]]).to(dev).contiguous()
     mark("x2 counts + straddling tokens")
     # this rank's checksum (its own range only), on its GPU -- before the block phase, whose device scalars
     # the pack kernel still reads
@@ -236,7 +272,7 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         csum = ctx.adler32_device(d_ext.data_ptr() + L["lo"], own)
     elif wrapper == 2:
         csum = ctx.crc32_device(d_ext.data_ptr() + L["lo"], own)
-    nb, carr = sh.blocks_raw(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank])
+    nb, carr = sh.blocks_raw(skip[rank], tail_t.data_ptr() if tail_t is not None else 0, tail[rank], owns[rank])
     mark("block costs")
     # round 3: one fixed-size record per rank: [block count, checksum, costs ...] as raw bytes
     csz = ctypes.sizeof(da.BlockCost)

@@ -188,6 +188,13 @@ int mi355_shard_exit_table(mi355_shard* s, uint32_t* table576);
 int mi355_shard_emit(mi355_shard* s, uint64_t entry, uint64_t* n_tokens, const void** d_tokens);
 int mi355_shard_blocks(mi355_shard* s, uint64_t skip_tokens, const void* d_tail_tokens, uint64_t n_tail,
                        uint64_t* n_blocks, mi355_block_cost* costs, size_t costs_cap);
+/* The same with the owner of the stream's last block named by the caller (owns_final != 0: this rank's tokens
+ * end in the last, possibly partial or empty, block; 0: it owns whole blocks only, possibly none).
+ * mi355_shard_blocks decides that by "is the last rank", which holds whenever every rank's range reaches the
+ * next block boundary; a range with fewer tokens than that belongs to a block that began several ranks to its
+ * left, and the tail a rank needs is then made of the heads of several ranks to its right. */
+int mi355_shard_blocks_ex(mi355_shard* s, uint64_t skip_tokens, const void* d_tail_tokens, uint64_t n_tail,
+                          int owns_final, uint64_t* n_blocks, mi355_block_cost* costs, size_t costs_cap);
 int mi355_plan_blocks(const mi355_block_cost* costs, size_t n, uint32_t compat, mi355_block_info* plans,
                       uint64_t* total_bits);
 int mi355_shard_pack(mi355_shard* s, const mi355_block_info* plans, uint64_t end_bit, void* d_out, size_t out_cap,

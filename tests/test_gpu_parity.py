@@ -406,6 +406,31 @@ def test_p1_sharded_stream_exact(da, world):
             c.close()
 
 
+def test_p1_sharded_ranges_shorter_than_a_block(da):
+    """Ranges that yield fewer tokens than it takes to reach the next block boundary own no block: their tokens
+    go to a block that began several ranks to the left, and that block's owner takes its tail from the heads of
+    several ranks (shard.p1_token_plan, mi355_shard_blocks_ex).  Round 1 refused such splits."""
+    import shard
+    world = 8
+    ctxs = [da.Context(0) for _ in range(world)]
+    try:
+        # (a rank's range is a multiple of 32 KiB: shard.shard_range)
+        cases = [("zeros", bytes(3_000_000), "default"),                      # ~1 400 tokens per rank
+                 ("zeros-small", bytes(300_000), "default"),                  # 127 tokens per rank
+                 ("text-small", datagen.text_like(300_000, 41), "default"),   # ~10 000 tokens per rank
+                 ("text-best", datagen.text_like(300_000, 42), "best"),
+                 ("period", (datagen.rng_bytes(300, 3) * 4000)[:1_000_000], "fast"),
+                 ("mixed", datagen.mixed(400_000, 43), "default")]
+        for name, data, level in cases:
+            c, l, m = LV[level]
+            ref = ob.encode(data, opts=ob.make_opts(c, l, m))
+            got = shard.encode_p1_virtual(da, ctxs, data, da.CompressionOptions(c, l, m), compat=1)
+            assert got == ref, "%s/%s: sharded stream differs (%d vs %d bytes)" % (name, level, len(got), len(ref))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def _p1_dist_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

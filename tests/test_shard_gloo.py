@@ -88,9 +88,27 @@ def test_p1_exchange_math():
         if r < 3:
             assert owned % shard.BLOCK_TOKENS == 0
     assert tail[:3] == skip[1:]
-    import pytest
-    with pytest.raises(ValueError):
-        shard.p1_token_split([100000, 5, 100000])
+    # a range that does not reach its next block boundary owns no block: all of its tokens go left, and the
+    # block they belong to takes the rest of what it needs from the rank after it
+    skip, tail, owns, pieces = shard.p1_token_plan([100000, 5, 100000])
+    B = shard.BLOCK_TOKENS
+    assert skip[1] == 5 and tail[1] == 0 and not owns[1]
+    assert tail[0] == (-100000) % B and pieces[0] == [(1, 5), (2, tail[0] - 5)]
+    assert skip[2] == tail[0] - 5 and owns == [False, False, True]
+    import random
+    rnd = random.Random(5)
+    for _ in range(3000):  # whole blocks everywhere but at the one owner of the last block; every block owned once
+        counts = [rnd.choice([0, 1, 7, B - 1, B, B + 1, rnd.randrange(0, 3 * B), rnd.randrange(0, 300)])
+                  for _ in range(rnd.randrange(1, 9))]
+        skip, tail, owns, pieces = shard.p1_token_plan(counts)
+        assert sum(owns) == 1
+        blocks = 0
+        for r, c in enumerate(counts):
+            own = c - skip[r] + tail[r]
+            assert sum(k for _, k in pieces[r]) == tail[r] and all(q > r for q, _ in pieces[r])
+            assert owns[r] or own % B == 0
+            blocks += own // B + (1 if owns[r] else 0)
+        assert blocks == sum(counts) // B + 1
     # entries: a rank whose range is jumped over keeps the incoming position
     lays = [dict(a=0, b=1000), dict(a=1000, b=1200), dict(a=1200, b=3000)]
     tabs = [[300] * shard.ZONE, [7] * shard.ZONE, [0] * shard.ZONE]
