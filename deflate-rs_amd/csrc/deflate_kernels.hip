@@ -3,14 +3,17 @@
 // One kernel per stage of stages.h; every kernel names the reference code it stands in for.
 // Layout of the per-encode workspace in HBM (n = input bytes, K = ceil(n / SEG) segments,
 // nb <= n / 31744 + 1 blocks):
-//   link   u16[n]      distance to the previous position with the same hash      2 B/byte
+//   S      u16[n]      per 32 KiB epoch: positions sorted by (filing hash, position)  2 B/byte   (k_sort -> k_match2)
+//   B      u16[32776 per epoch]  start of every hash bucket in the epoch's S       2 B/byte
+//   link   u16[n]      distance to the previous position with the same hash (k_links -> k_match: the first two
+//                      epochs of a re-warmed stream, streams with late-filed positions, budgets under 16)
 //   M, Mq  u32[n]      longest_match(prev_length = 0) at full / quarter budget   4 (+4) B/byte
 //   adv    u16[n]      restart step length from every position                   2 B/byte
 //   J      u16[n]      scratch of the per-segment exit sweep                     2 B/byte
 //   X[l]   u16[K_l*ZONE]  exit tables per level (an exit lies less than MAX_JUMP beyond its unit), E[l] u32[K_l] entry positions
 //   tokbuf u32[K*SEG]  tokens per segment, dtok u32[T] tokens in stream order    4 + 4 B/byte
-//   per block: ll_freq u32[288], d_freq u32[32], BlockHeader, BlockPlan, bstart
-// All integer work; the bound is LDS/issue rate in k_match and HBM elsewhere.
+//   per block: ll_freq u32[4][288], d_freq u32[4][32] (a histogram per quarter of the block), BlockHeader, BlockPlan, bstart
+// All integer work; the bound is vector-ALU issue / LDS in k_match2 and latency or HBM elsewhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
