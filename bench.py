@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--level", default="", choices=["", "default", "best", "fast", "rle", "huffman_only"],
                     help="override the level of the workload (default: Default, rle() for zeros)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the value_host_api leg (profiling runs: every kernel row is then one launch shape)")
+    ap.add_argument("--pmc-file", default="", help="PMC summary to take roofline.traffic from (default: newest profiles/r*_pmc_summary.json)")
     args = ap.parse_args()
 
     import torch
@@ -261,11 +264,20 @@ def main():
         # the committed PMC passes of this very command (profiles/, FETCH_SIZE doubled as the guide prescribes)
         traffic = None
         lds_conflict = None
+        pmc_source = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")))
-            if pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1:
-                traffic = pm["kernels"][dominant]["hbm_bytes"]
-                lds_conflict = pm["kernels"][dominant].get("lds_bank_conflict_rate")
+            import glob
+            cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            pm = json.load(open(cands[-1]))
+            k = pm["kernels"][dominant]
+            # a summary is only taken when it is of this very workload and every counter of the kernel was
+            # averaged over launches of ONE shape: launches == steps of the profiled command (the host-API leg,
+            # which launches the kernel on pieces of the input, must have been off)
+            if (pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1
+                    and pm.get("launches_per_pass") == k.get("launches") and k.get("launches")):
+                traffic = k["hbm_bytes"]
+                lds_conflict = k.get("lds_bank_conflict_rate")
+                pmc_source = os.path.relpath(cands[-1], ROOT)
         except Exception:
             pass
         # the kernel that reads the input coalesced: k_sort files every position under its hash (reads n, writes
@@ -275,9 +287,13 @@ def main():
         in_bytes = size * 5
         input_load = None
         if links_ms > 0 and lvl not in ("rle", "huffman_only"):
-            input_load = {"kernel": in_kernel, "bytes": in_bytes, "ms": round(links_ms, 3),
-                          "achieved": round(in_bytes / (links_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                          "frac": round(in_bytes / (links_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # twice: the input bytes alone (no credit for intermediates), and with the sorted
+            # array and bucket starts the kernel writes (2 B per position each)
+            input_load = {"kernel": in_kernel, "ms": round(links_ms, 3), "unit": "GB/s",
+                          "input_only": {"bytes": size, "achieved": round(size / (links_ms * 1e-3) / 1e9, 1),
+                                         "frac": round(size / (links_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                          "with_intermediates": {"bytes": in_bytes, "achieved": round(in_bytes / (links_ms * 1e-3) / 1e9, 1),
+                                                 "frac": round(in_bytes / (links_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         res = {
             "metric": "MB/s raw input encoded (%s) + compressed size vs ref" % level_name,
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,11 +311,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes,
-                         "input_load": input_load, "lds_bank_conflict_rate": lds_conflict},
+                         "input_load": input_load, "lds_bank_conflict_rate": lds_conflict, "pmc_source": pmc_source},
         }
         if p1_trace is not None:
             res["p1_phases_ms_rank0"] = p1_trace  # (one untimed step, synchronised per phase)
-        if world == 1:
+        if world == 1 and not args.no_host_api:
             # the drop-in call itself, deflate_bytes(&[u8]) -> Vec<u8> (src/lib.rs:163): pinned host buffers,
             # first H2D byte to last D2H byte inside the timed region
             h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
@@ -314,7 +330,8 @@ def main():
             res["value_host_api"] = {"value": round(size * reps / dt / 1e6, 2), "unit": "MB/s",
                                      "ms_per_call": round(dt * 1e3 / reps, 3),
                                      "what": "mi355_deflate_encode on pinned host buffers, H2D + encode + D2H",
-                                     "same_bytes": bool(hn == out_len[0])}
+                                     "same_bytes": bool(hn == out_len[0] and torch.equal(
+                                         h_out[:hn], d_out[:hn].cpu()))}
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
             olvl = {"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST, "rle": ob.RLE,

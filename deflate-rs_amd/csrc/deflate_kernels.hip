@@ -592,7 +592,7 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
 }
 
 __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
-                                               uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0) {
+                                               uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl) {
     __shared__ __attribute__((aligned(16))) uint16_t sH[WINDOW_SIZE];  // hashes; the sorted array at the end
     __shared__ __attribute__((aligned(16))) uint32_t sBuf[WINDOW_SIZE / 2];  // histogram (u16 pairs), then pass-1 output (u16)
     __shared__ uint32_t sCnt[16 * 256];
@@ -673,7 +673,12 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
     uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
     const uint4* fin = reinterpret_cast<const uint4*>(sH);
-    for (uint32_t k = tid; k < (J + 7) / 8; k += 1024) out[k] = fin[k];
+    // dbl = 1: entries as 2 * position (k_match3 adds them to a pair-table address); positions are below 32768,
+    // so the shift of a whole word moves nothing across its halves
+    for (uint32_t k = tid; k < (J + 7) / 8; k += 1024) {
+        const uint4 v = fin[k];
+        out[k] = make_uint4(v.x << dbl, v.y << dbl, v.z << dbl, v.w << dbl);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,6 +964,262 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
         if (HAS_Q) Mq[E + pend_at] = pend_mq;
     }
 #endif
+#ifdef MI355_MATCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match3: matching.rs:87-166 for the positions of one epoch, in the order of S_e like k_match2, with the
+// window held in LDS as a table of byte PAIRS (stages.h SwG): the probe of a candidate is ONE aligned
+// two-byte read -- k_match2's two one-byte reads cost two trips through the LDS banks per visit, and the LDS
+// array was 76 % busy, half of it bank conflicts -- and the step block asks about four candidates at a time:
+// four address adds, four reads in flight, four compares that shrink EXEC, and the bookkeeping (entry offset,
+// window, entries left) once per group instead of once per step.  The table is 2 B per position of the
+// previous and the own epoch: 131.6 KB, one workgroup of 16 waves per CU (k_match2: two of them at 64 KB).
+// ---------------------------------------------------------------------------------------------
+#ifndef MI355_M3_GROUPS
+#define MI355_M3_GROUPS 3
+#endif
+constexpr uint32_t M3T = 1024;
+constexpr uint32_t M3_PAIRS = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16: pairs in the table (= bytes staged)
+static_assert(MI355_M3_GROUPS >= 2 && MI355_M3_GROUPS <= 4, "two to four groups of four steps");
+
+struct PairWin {
+    const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array (entries are 2 * position)
+    uint32_t tbase;      // LDS address of T[0]
+    typedef __attribute__((address_space(3))) const uint16_t* lds_u16;
+    __device__ uint32_t pair_at(uint32_t a) const { return *(lds_u16)a; }
+    // 16 bytes from position pos on: the 40 aligned table bytes that hold T[pos & ~3 ...] are twenty pairs, every
+    // other one of them -- the low half of each dword -- new bytes; five 8-byte reads (the 64-bank form), the
+    // halves packed by byte selects, then the shift by pos & 3
+    __device__ void load16(uint32_t pos, uint32_t* q) const {
+        // (written out: the compiler pairs neighbouring 8-byte reads into ds_read2_b64, which takes four times the
+        // LDS cycles of two ds_read_b64 -- MI355X_MICROARCH.md, LDS table)
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 d0, d1, d2, d3, d4;
+        const uint32_t a8 = (tbase + 2 * pos) & ~7u;
+        asm volatile(
+            "ds_read_b64 %0, %5\n\t"
+            "ds_read_b64 %1, %5 offset:8\n\t"
+            "ds_read_b64 %2, %5 offset:16\n\t"
+            "ds_read_b64 %3, %5 offset:24\n\t"
+            "ds_read_b64 %4, %5 offset:32\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4)
+            : "v"(a8)
+            : "memory");
+        const uint32_t w0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x05040100u), w1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x05040100u),
+                       w2 = __builtin_amdgcn_perm(d2.y, d2.x, 0x05040100u), w3 = __builtin_amdgcn_perm(d3.y, d3.x, 0x05040100u),
+                       w4 = __builtin_amdgcn_perm(d4.y, d4.x, 0x05040100u);
+        q[0] = __builtin_amdgcn_alignbyte(w1, w0, pos);
+        q[1] = __builtin_amdgcn_alignbyte(w2, w1, pos);
+        q[2] = __builtin_amdgcn_alignbyte(w3, w2, pos);
+        q[3] = __builtin_amdgcn_alignbyte(w4, w3, pos);
+    }
+    __device__ uint32_t load32(uint32_t pos) const {
+        lds_u16 t = (lds_u16)(tbase + 2 * pos);
+        return (uint32_t)t[0] | ((uint32_t)t[2] << 16);
+    }
+    __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
+};
+
+// A block of MI355_M3_GROUPS groups of four chain steps (stages.h swg_group_ref) for the lanes of `walk`.  Per
+// group: the four entries of one 8-byte load become four probe addresses (16-bit operand selects of the
+// load's registers, fixed v56..v59), the four two-byte reads are issued back to back, and each answer shrinks
+// EXEC when it matches the lane's probe; then the window test on the last address and "entries left".  A lane
+// that leaves keeps a0..a3 / t0..t3 of its last group, offb already a group further: the service finds out
+// where it stopped.  The next group's entries are loaded while this one's answers arrive.
+#define M3_GROUP(LO, HI, MID)                                                                                         \
+    "v_add_u32_sdwa %[a0], " HI ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"      \
+    "v_add_u32_sdwa %[a1], " HI ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"      \
+    "v_add_u32_sdwa %[a2], " LO ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"      \
+    "v_add_u32_sdwa %[a3], " LO ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"      \
+    "ds_read_u16 %[t0], %[a0]\n\t"                                                                                    \
+    "ds_read_u16 %[t1], %[a1]\n\t"                                                                                    \
+    "ds_read_u16 %[t2], %[a2]\n\t"                                                                                    \
+    "ds_read_u16 %[t3], %[a3]\n\t"                                                                                    \
+    "v_add_u32_e32 %[offb], -8, %[offb]\n\t"                                                                          \
+    MID                                                                                                               \
+    "s_waitcnt lgkmcnt(3)\n\t"                                                                                        \
+    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"                                                                      \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                        \
+    "v_cmpx_ne_u32_e32 vcc, %[t1], %[probe]\n\t"                                                                      \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                        \
+    "v_cmpx_ne_u32_e32 vcc, %[t2], %[probe]\n\t"                                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                        \
+    "v_cmpx_ne_u32_e32 vcc, %[t3], %[probe]\n\t"                                                                      \
+    "v_cmpx_ge_u32_e32 vcc, %[a3], %[lowa]\n\t"                                                                       \
+    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"                                                                     \
+    "s_cbranch_execz .Lm3_end%=\n\t"
+
+template <bool HAS_Q>
+__device__ __forceinline__ uint64_t m3_steps(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {
+    uint64_t save, still;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[walk]\n\t"
+        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"   // entries off-3 .. off
+        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"  // entries off-7 .. off-4
+        "s_waitcnt vmcnt(1)\n\t"
+#if MI355_M3_GROUPS >= 3
+        M3_GROUP("v56", "v57", "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t")  // (offb has moved on by four entries)
+        "s_waitcnt vmcnt(1)\n\t"
+#else
+        M3_GROUP("v56", "v57", "")
+        "s_waitcnt vmcnt(0)\n\t"
+#endif
+#if MI355_M3_GROUPS >= 4
+        M3_GROUP("v58", "v59", "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t")
+        "s_waitcnt vmcnt(1)\n\t"
+#else
+        M3_GROUP("v58", "v59", "")
+        "s_waitcnt vmcnt(0)\n\t"
+#endif
+#if MI355_M3_GROUPS >= 3
+        M3_GROUP("v56", "v57", "")
+#endif
+#if MI355_M3_GROUPS >= 4
+        "s_waitcnt vmcnt(0)\n\t"
+        M3_GROUP("v58", "v59", "")
+#endif
+        ".Lm3_end%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 %[still], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [offb] "+v"(s.offb), [a0] "+v"(s.a0), [a1] "+v"(s.a1), [a2] "+v"(s.a2), [a3] "+v"(s.a3), [t0] "+v"(s.t0),
+          [t1] "+v"(s.t1), [t2] "+v"(s.t2), [t3] "+v"(s.t3), [save] "=&s"(save), [still] "=&s"(still)
+        : [bb] "v"(s.bb2), [lowa] "v"(s.lowa2), [probe] "v"(s.probe), [endb] "v"(s.endb), [sb] "s"(sb8), [walk] "s"(walk)
+        : "vcc", "memory", "v56", "v57", "v58", "v59");
+    return still;
+}
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
+                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split) {
+    __shared__ __attribute__((aligned(16))) uint4 s_T[M3_PAIRS / 8];  // T[k] = byte k | byte k+1 << 8, k from the window's start
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
+    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
+    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
+    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
+    // stage the window: 16 bytes and the byte behind them make 16 pairs = two 16-byte stores
+    for (uint32_t w = tid; w < wbytes / 16; w += M3T) {
+        const uint64_t g = wbase + 16ull * w;
+        uint32_t t[5] = {0, 0, 0, 0, 0};
+        if (in_aligned16 && g + 20 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(in + g);
+            t[0] = v.x;
+            t[1] = v.y;
+            t[2] = v.z;
+            t[3] = v.w;
+            t[4] = *reinterpret_cast<const uint32_t*>(in + g + 16);
+        } else {
+            for (int b = 0; b < 17; b++)
+                if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
+        }
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[2 * k] = __builtin_amdgcn_perm(t[k], t[k], 0x02010100u);          // b0 b1 | b1 b2
+            o[2 * k + 1] = __builtin_amdgcn_perm(t[k + 1], t[k], 0x04030302u);  // b2 b3 | b3 b4
+        }
+        s_T[2 * w] = make_uint4(o[0], o[1], o[2], o[3]);
+        s_T[2 * w + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    const uint32_t J = epoch_active(n, E);
+    const uint32_t nbat = (J + 63) / 64;
+    const uint32_t b_lo = (uint32_t)((uint64_t)nbat * part / split), b_hi = (uint32_t)((uint64_t)nbat * (part + 1) / split);
+    if (tid == 0) s_next = b_lo;
+    if (part == 0 && tid < 2) {  // the positions without a hash byte (the last two of the input) are never searched
+        const uint64_t p = E + J + tid;
+        if (p < n && p < E + WINDOW_SIZE) {
+            M[p] = 0;
+            if (HAS_Q) Mq[p] = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_T;
+    const uint32_t bias = (uint32_t)(E - wbase);  // position of the own epoch's first byte in the window
+    // (the array pointer may lie before the array for epoch 0; only indices >= 32768 - 7 are read then, and
+    // the array has a pad in front)
+    const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;
+    PairWin win{sbase, tbase};
+    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
+    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
+    const uint16_t* Bprev = Bown - BSTRIDE;
+    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
+#ifdef MI355_MATCH_STATS
+    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    M2_T0
+    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= b_hi) break;
+        const uint32_t j = b * 64 + lane;
+        const bool valid = j < J;
+        SwG<HAS_Q> st;
+        uint32_t srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
+        if (valid) {
+            srel = (uint32_t)own[j] >> 1;
+            prel = bias + srel;
+            const uint32_t v = win.load32(prel);
+            const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
+            const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
+            ob = Bown[h];
+            if (e) {
+                pb0 = Bprev[h];
+                pb1 = Bprev[h + 1];
+            }
+            nrel = lim(prel);
+        }
+        // (one call for all lanes: the lane masks it sets must be ballots of the whole wave)
+        (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
+        st.done = ~st.walk;
+        M2_CNT(0, 1)
+        M2_T(8)
+        // (the results of the batch before go out here, behind this batch's set-up loads: see k_match2)
+        if (pend_at != ~0u) {
+            M[E + pend_at] = pend_m;
+            if (HAS_Q) Mq[E + pend_at] = pend_mq;
+        }
+        // the first candidate of every lane goes straight to the service
+        uint64_t dropped = swg_first(st, win);
+        for (;;) {
+            if (dropped) {
+                const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe) & dropped;
+                const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & dropped & ~e0m;
+                const uint64_t e2m = __builtin_amdgcn_ballot_w64(st.t2 == st.probe) & dropped & ~(e0m | e1m);
+                const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & dropped & ~(e0m | e1m | e2m);
+                M2_CNT(2, 1)
+                M2_CNT(3, __popcll(dropped))
+                swg_service(st, win, tbase, checks_q, dropped, e0m, e1m, e2m, e3m, st.a0, st.a1, st.a2, st.a3);
+                M2_T(9)
+            }
+            const uint64_t walk = st.walk;
+            if (walk == 0) break;
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(walk))
+            const uint64_t still = m3_steps(st, sbase - 4, walk);
+            M2_T(12)
+            st.walk = still;
+            dropped = walk & ~still;
+        }
+        swg_result(st, &pend_m, &pend_mq);
+        pend_at = valid ? srel : ~0u;
+        M2_T(13)
+    }
+    if (pend_at != ~0u) {
+        M[E + pend_at] = pend_m;
+        if (HAS_Q) Mq[E + pend_at] = pend_mq;
+    }
 #ifdef MI355_MATCH_STATS
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);

@@ -986,6 +986,201 @@ MI355_HD void swl_result(const SwLean<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
     *mq = (HAS_Q && lf_me(s.hq)) ? s.mq : r;
 }
 
+// ---- the sorted walk, third form (k_match3): pair table, probes four at a time -------------------------
+// What longest_match computes for prev_length = 0 is a pure function of the candidate list: among the first
+// K candidates of the chain that lie within 32768 bytes (matching.rs:119-132), the one with the longest
+// common prefix with P, the nearest among equals, if that prefix is at least 2 bytes (matching.rs:149-156
+// only ever replaces the best by a strictly longer one).  The two-byte probe at best-1, best
+// (matching.rs:141-143) never rejects a candidate that would improve the result, so ANY test that passes
+// every candidate the probe passes gives the same answer: a candidate looked at in vain is compared and
+// dropped.  k_match3 uses that freedom in one place only -- it reads the probe bytes of FOUR consecutive
+// candidates before it looks at the first answer, so a lane that finds a hit has asked about up to three
+// candidates it does not need yet (and, at the end of a run, about up to three entries beyond it, which the
+// service discards by index).  Everything else is the walk of SwLean above, with these changes:
+//   * the window's bytes sit in LDS as a table of PAIRS, T[k] = byte k | byte k+1 << 8: the probe is one
+//     aligned two-byte read at any k (the byte image needed two one-byte reads and a shift per candidate),
+//     and the sorted arrays hold 2 * position, so that entry + bb2 IS the address of the probe;
+//   * a lane's candidates are at most two SEGMENTS fixed at set-up -- its own epoch's bucket below it, cut
+//     to the budget, then the previous epoch's bucket, cut to what is left -- so the step only tests
+//     "entries left", once per group, and the window (matching.rs:102-106), once per group;
+//   * the quarter result of lz77.rs:351-355 is taken when the first hit beyond the quarter budget is
+//     settled (or the final result, when there is none): no run ends there.
+// Coordinates: positions count from the window's first byte (`org` = 0); probe addresses are LDS addresses
+// tbase + 2 * position (tbase = 0 on the host).
+template <bool HAS_Q>
+struct SwG {
+    uint32_t offb, endb, bb2, lowa2, probe;  // the registers of the step block (offb = 2 * index + 8 of the next entry)
+    uint32_t a0, a1, a2, a3, t0, t1, t2, t3;  // probe addresses and probe bytes of the last group (named: an array
+                                             // selected by lane masks ends up in scratch memory on the GPU)
+    uint32_t prel, maxlen, p16[4], bm1, bestd, low;
+    uint32_t offb2, endb2;                   // the segment in the previous epoch's bucket (none: offb2 < endb2)
+    uint32_t seg0, vbase, mq;                // HAS_Q: offset of the segment's first entry, candidates of the segment before
+    lane_flag walk, done, in_prev, hq;
+};
+
+// Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the previous
+// epoch (pb0 == pb1 for epoch 0).  prel / nrel: position and end of the visible data, `bias` = position of the
+// own epoch's first byte.  Returns whether the position is searched at all (lz77.rs:294-301); s.walk = it has
+// candidates.
+template <bool HAS_Q, class W>
+MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1, uint32_t prel,
+                        uint32_t nrel, uint32_t tbase, uint32_t bias, uint32_t checks, uint32_t checks_q) {
+    s.prel = prel;
+    s.low = prel > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : 0u;
+    s.bm1 = 0;
+    s.bestd = 0;
+    s.mq = 0;
+    s.vbase = 0;
+    s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
+    s.done = lf_of(false);
+    s.a0 = s.a1 = s.a2 = s.a3 = tbase;
+    s.t0 = s.t1 = s.t2 = s.t3 = 0;
+    const bool search = prel + 2 < nrel && checks > 0;
+    const uint32_t left = nrel - prel;
+    s.maxlen = search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u;
+    uint32_t n1 = j - own_b0;
+    n1 = n1 < checks ? n1 : checks;
+    uint32_t n2 = pb1 - pb0;
+    n2 = n2 < checks - n1 ? n2 : checks - n1;
+    s.offb2 = 2 * (pb1 - 1) + 8;
+    s.endb2 = s.offb2 + 2 - 2 * n2;  // (n2 == 0: one beyond the first entry)
+    const bool own = n1 > 0;
+    s.offb = own ? 2 * (SW_OWN + j - 1) + 8 : s.offb2;
+    s.endb = own ? s.offb + 2 - 2 * n1 : s.endb2;
+    s.in_prev = lf_of(!own);
+    s.seg0 = s.offb;
+    s.bb2 = tbase + 2 * (own ? bias : 0u);
+    s.lowa2 = tbase + 2 * s.low;
+    w.load16(prel, s.p16);
+    s.probe = s.p16[0] & 0xffffu;
+    s.walk = lf_of(search && n1 + n2 > 0);
+    return search;
+}
+
+// The first candidate of every lane that walks is settled without a step: same-bucket entries nearly always
+// share the first two bytes, so the lanes would all leave their first group at its first probe.  Pretends
+// that group: a[0] / t[0] of a hit, offb a group further.  Returns the lanes concerned (the d0 of swg_service).
+template <bool HAS_Q, class W>
+MI355_HD lane_flag swg_first(SwG<HAS_Q>& s, const W& w) {
+    const lane_flag st = s.walk;
+    uint32_t e2 = 0;
+    if (lf_me(st)) e2 = w.sidx((uint32_t)((int32_t)(s.offb - 8) >> 1));
+    s.a0 = lf_me(st) ? e2 + s.bb2 : s.a0;
+    s.t0 = lf_me(st) ? s.probe : s.t0;
+    s.offb -= lf_me(st) ? 8u : 0u;
+    s.walk = lf_of(false);
+    return st;
+}
+
+// One group of four steps of a walking lane (host twin of the GPU's step block): the four entries from offb
+// downwards, their probe reads, then the tests in the GPU's order -- probe 0..3 (the first hit ends it:
+// `d` = its number), window of the last, entries left.  A lane that leaves keeps a[] / t[] of this group.
+template <bool HAS_Q, class W>
+MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d) {
+    *d = -1;
+    if (!lf_me(s.walk)) return;
+    const int32_t idx = (int32_t)(s.offb - 8) >> 1;
+    s.a0 = w.sidx((uint32_t)idx) + s.bb2;
+    s.a1 = w.sidx((uint32_t)(idx - 1)) + s.bb2;
+    s.a2 = w.sidx((uint32_t)(idx - 2)) + s.bb2;
+    s.a3 = w.sidx((uint32_t)(idx - 3)) + s.bb2;
+    s.t0 = w.pair_at(s.a0);
+    s.t1 = w.pair_at(s.a1);
+    s.t2 = w.pair_at(s.a2);
+    s.t3 = w.pair_at(s.a3);
+    s.offb -= 8;
+    const int hit = s.t0 == s.probe ? 0 : (s.t1 == s.probe ? 1 : (s.t2 == s.probe ? 2 : (s.t3 == s.probe ? 3 : -1)));
+    if (hit >= 0) {
+        *d = hit;
+        s.walk = lf_of(false);
+        return;
+    }
+    if (s.a3 < s.lowa2 || (int32_t)s.offb < (int32_t)s.endb) s.walk = lf_of(false);
+}
+
+// Settle the lanes that left the last block (`dropped`; d0..d3 = those that left at the probe of step 0..3 of
+// their last group, the others left at its end).  Straight-line selects; only a match longer than 16 bytes loops.
+template <bool HAS_Q, class W>
+MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag d0,
+                          lane_flag d1, lane_flag d2, lane_flag d3, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+    // (a0..a3 = s.a0..s.a3, by value: a select among neighbouring fields of a struct behind a reference is turned
+    // into a load through a selected pointer, and the whole struct then lives in scratch memory on the GPU)
+    // which entry: a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of
+    // the window (positions fall along a segment, so the hit's own address tells), is no hit
+    const lane_flag dany = d0 | d1 | d2 | d3;
+    const uint32_t asel = lf_me(d0) ? a0 : (lf_me(d1) ? a1 : (lf_me(d2) ? a2 : a3));
+    const uint32_t back = lf_me(d0) ? 8u : (lf_me(d1) ? 6u : (lf_me(d2) ? 4u : 2u));
+    const uint32_t ho = s.offb + back;  // offset of the entry in question
+    const lane_flag hit = dany & lf_of((int32_t)ho >= (int32_t)s.endb && asel >= s.lowa2);  // matching.rs:102-106,127,141-143
+    lane_flag rend = lf_and_not(dropped, hit);  // the segment is used up, or its next candidate is out of reach
+    // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
+    const uint32_t cpos = ((asel - tbase) >> 1) - s.bm1;
+    uint32_t q[4];
+    w.load16(cpos, q);
+    const uint32_t b0 = (uint32_t)(__builtin_ffs((int)(q[0] ^ s.p16[0])) - 1);
+    const uint32_t b1 = (uint32_t)(__builtin_ffs((int)(q[1] ^ s.p16[1])) - 1) | 32u;
+    const uint32_t b2 = (uint32_t)(__builtin_ffs((int)(q[2] ^ s.p16[2])) - 1) | 64u;
+    const uint32_t b3 = (uint32_t)(__builtin_ffs((int)(q[3] ^ s.p16[3])) - 1) | 96u;
+    uint32_t bits = b0 < b1 ? b0 : b1;
+    const uint32_t bh = b2 < b3 ? b2 : b3;
+    bits = bits < bh ? bits : bh;
+    uint32_t len = (bits < 128u ? bits : 128u) >> 3;
+    const lane_flag lng = hit & lf_of(len == 16 && s.maxlen > 16);
+    if (lf_any(lng)) {
+        if (lf_me(lng)) {
+            while (len < s.maxlen) {
+                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(cpos + len + 4)) << 32) |
+                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(cpos + len));
+                if (x) {
+                    len += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                len += 8;
+            }
+        }
+    }
+    len = len < s.maxlen ? len : s.maxlen;
+    if (HAS_Q) {  // lz77.rs:351-355: the state after max_hash_checks >> 2 iterations, taken before the first later hit counts
+        const uint32_t rank = s.vbase + ((s.seg0 - ho) >> 1) + 1;
+        const lane_flag cap = lf_and_not(hit, s.hq) & lf_of(rank > checks_q);
+        s.mq = lf_me(cap) ? m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd) : s.mq;
+        s.hq = s.hq | cap;
+    }
+    const lane_flag imp = hit & lf_of(len > s.bm1 + 1);  // matching.rs:149-156
+    const uint32_t delta = lf_me(imp) ? len - 1 - s.bm1 : 0u;
+    s.bestd = lf_me(imp) ? s.prel - cpos : s.bestd;
+    s.bm1 += delta;
+    s.bb2 += 2 * delta;
+    s.lowa2 += 2 * delta;
+    const lane_flag full = imp & lf_of(len == s.maxlen);
+    const uint32_t pr = w.pair_at(tbase + 2 * (s.prel + s.bm1));
+    s.probe = lf_me(imp) ? pr : s.probe;
+    s.offb = lf_me(hit) ? ho - 2 : s.offb;
+    const lane_flag more = lf_of((int32_t)s.offb >= (int32_t)s.endb);
+    const lane_flag hgo = lf_and_not(hit, full);
+    rend = rend | lf_and_not(hgo, more);
+    const lane_flag resume = hgo & more;
+    // end of the own epoch's segment: on to the previous epoch's bucket, if the budget reaches it
+    const lane_flag sw = lf_and_not(rend, s.in_prev) & lf_of((int32_t)s.offb2 >= (int32_t)s.endb2);
+    s.done = s.done | full | lf_and_not(rend, sw);
+    if (HAS_Q) {
+        s.vbase += lf_me(sw) ? ((s.seg0 - s.endb) >> 1) + 1 : 0u;
+        s.seg0 = lf_me(sw) ? s.offb2 : s.seg0;
+    }
+    s.offb = lf_me(sw) ? s.offb2 : s.offb;
+    s.endb = lf_me(sw) ? s.endb2 : s.endb;
+    s.bb2 = lf_me(sw) ? tbase + 2 * s.bm1 : s.bb2;
+    s.in_prev = s.in_prev | sw;
+    s.walk = lf_and_not(s.walk | resume | sw, s.done);
+}
+
+template <bool HAS_Q>
+MI355_HD void swg_result(const SwG<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
+    const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
+    *m = r;
+    *mq = (HAS_Q && lf_me(s.hq)) ? s.mq : r;
+}
+
 // ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------
 // R[p] = number of bytes from p equal to data[p-1], capped at 258 and at the end of input; 0 if
 // p == 0 or data[p] != data[p-1].

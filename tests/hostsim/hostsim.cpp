@@ -81,7 +81,7 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
-    if (g_multi == 4 || g_multi == 5) {
+    if (g_multi == 4 || g_multi == 5 || g_multi == 6) {
         // the k_sort + k_match2 formulation: epochs sorted by (hash, position), lanes walk runs of the
         // sorted arrays (stages.h SortedLane); step / service alternate as on the GPU
         const uint32_t W = WINDOW_SIZE;
@@ -161,7 +161,54 @@ void stage_match(Sim& s) {
                     }
                     swl_result(ln, &m, &mq);
                 };
-                if (g_multi == 5) {
+                // the k_match3 form: pair table, groups of four probes, the service decodes where a lane stopped
+                struct PWin {
+                    const uint8_t* d;  // position 0 of the window
+                    uint64_t nb;       // readable bytes from d
+                    const uint16_t* ps;
+                    const uint16_t* cs;
+                    uint32_t np, nc;
+                    uint32_t byte(uint64_t k) const { return k < nb ? d[k] : 0u; }
+                    uint32_t pair_at(uint32_t a) const { return byte(a >> 1) | (byte((a >> 1) + 1) << 8); }  // (tbase = 0)
+                    uint32_t load32(uint32_t k) const { return byte(k) | (byte(k + 1) << 8) | (byte(k + 2) << 16) | (byte(k + 3) << 24); }
+                    void load16(uint32_t k, uint32_t* q) const {
+                        for (int i = 0; i < 4; i++) q[i] = load32(k + 4 * i);
+                    }
+                    uint32_t sidx(uint32_t i) const {  // entries are 2 * position (k_sort with dbl = 1)
+                        if (i >= SW_OWN) return i - SW_OWN < nc ? 2u * cs[i - SW_OWN] : 0u;
+                        return i < np ? 2u * ps[i] : 0u;
+                    }
+                };
+                auto run6 = [&](auto& ln) {
+                    PWin pw{s.in.data() + wbase, (uint64_t)s.in.size() - wbase, prevS.data(), curS.data(), (uint32_t)prevS.size(),
+                            (uint32_t)curS.size()};
+                    (void)swg_setup(ln, pw, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
+                    ln.done = lf_not(ln.walk);
+                    lane_flag dropped = (j % 3) ? swg_first(ln, pw) : lf_of(false);  // (with and without the short cut)
+                    int d = dropped ? 0 : -1;
+                    uint32_t guard = 0;
+                    for (;;) {
+                        if (lf_me(dropped))
+                            swg_service(ln, pw, 0u, cq, dropped, lf_of(d == 0), lf_of(d == 1), lf_of(d == 2), lf_of(d == 3), ln.a0, ln.a1,
+                                        ln.a2, ln.a3);
+                        if (!lf_me(ln.walk)) break;
+                        const uint32_t groups = 1 + (guard % 3);
+                        d = -1;
+                        for (uint32_t g = 0; g < groups && lf_me(ln.walk); g++) swg_group_ref(ln, pw, &d);
+                        dropped = lf_not(ln.walk);
+                        if (++guard > 100000) break;
+                    }
+                    swg_result(ln, &m, &mq);
+                };
+                if (g_multi == 6) {
+                    if (hasq) {
+                        SwG<true> ln;
+                        run6(ln);
+                    } else {
+                        SwG<false> ln;
+                        run6(ln);
+                    }
+                } else if (g_multi == 5) {
                     if (hasq) {
                         SwLean<true> ln;
                         run5(ln);

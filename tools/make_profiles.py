@@ -1,7 +1,9 @@
 """Run on the GPU box from the repo root: the rocprofv3 evidence behind the bench line.
   python tools/make_profiles.py TAG        -> gpurun_out/TAG_kernel_stats.txt, TAG_pmc_summary.json, TAG_bench.json
 (copy them into profiles/).  Kernel trace and the counter passes are separate runs of the same command,
-`python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (trace) / `--steps 1 --warmup 0` (counters);
+`python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api` (trace) / `--steps 1 --warmup 0` (counters:
+one launch of every kernel, all of one shape -- the host-API leg, which launches the match kernels on pieces of
+the input, is off; the summary records the launch count per kernel and bench.py refuses a file where it differs);
 FETCH_SIZE and WRITE_SIZE in passes of their own, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)."""
 import csv
 import glob
@@ -16,6 +18,7 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 EXTRA = sys.argv[2:]
 OUT = os.path.join(ROOT, "gpurun_out")
 ENV = dict(os.environ, TMPDIR="/tmp")
+LAUNCHES = {}  # kernel -> launches per counter pass
 
 
 def short(name):
@@ -28,7 +31,7 @@ def rocprof(args, sub):
     d = os.path.join(OUT, "%s_%s" % (TAG, sub))
     subprocess.run("rm -rf " + d, shell=True)
     cmd = ["rocprofv3"] + args + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                                  "--no-cpu-baseline"] + EXTRA
+                                  "--no-cpu-baseline", "--no-host-api"] + EXTRA
     subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     return d
 
@@ -43,6 +46,8 @@ def pmc(counters, steps_args):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             seen[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
     subprocess.run("rm -rf " + d, shell=True)
+    for (k, cn), ids in seen.items():
+        LAUNCHES[k] = max(LAUNCHES.get(k, 0), len(ids))
     return {k: {c: v / max(1, len(seen[(k, c)])) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -55,7 +60,7 @@ def main():
     f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(OUT, TAG + "_kernel_stats.txt"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline %s\n" % " ".join(base_extra))
+        o.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-api %s\n" % " ".join(base_extra))
         o.write("%-28s %6s %12s %12s %12s %8s\n" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
         for r in rows:
             o.write("%-28s %6s %12.1f %12.1f %12.1f %8.2f\n" % (short(r["Name"])[:28], r["Calls"], float(r["AverageNs"]) / 1e3,
@@ -71,7 +76,7 @@ def main():
     wr = pmc(["WRITE_SIZE"], None)
     # the bench line of an unprofiled run
     EXTRA = base_extra + ["--steps", "5", "--warmup", "2"]
-    line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + EXTRA, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+    line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-file", "/nonexistent"] + EXTRA, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
     open(os.path.join(OUT, TAG + "_bench.json"), "w").write(line + "\n")
     bl = json.loads(line)
     n = bl["config"]["bytes_per_gpu"]
@@ -89,6 +94,7 @@ def main():
         if "SQ_INSTS_VALU" in e:
             e["valu_wave_instr_per_input_byte"] = round(e["SQ_INSTS_VALU"] / n, 3)
             e["salu_wave_instr_per_input_byte"] = round(e.get("SQ_INSTS_SALU", 0.0) / n, 3)
+        e["launches"] = LAUNCHES.get(k, 0)
         if k in stats:
             e["avg_us_kernel_trace"] = round(stats[k], 1)
             if e["hbm_bytes"]:
@@ -96,14 +102,14 @@ def main():
         kernels[k] = e
     lvl = bl["config"]["level"]
     json.dump({"note": "rocprofv3 --pmc passes (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE: four separate runs) over `python bench.py "
-                       "--steps 1 --warmup 0 --no-cpu-baseline`; per launch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
+                       "--steps 1 --warmup 0 --no-cpu-baseline --no-host-api`; per launch (launches = dispatches of the kernel in a pass); hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                        "(FETCH_SIZE doubled per MI355X_MICROARCH.md); durations from the --kernel-trace run",
                "workload": bl["config"]["workload"].split(":")[0], "bytes_per_gpu": n,
                "level": {"Compression::Default": "default", "Compression::Best": "best", "Compression::Fast": "fast", "rle()": "rle",
                          "huffman_only()": "huffman_only"}[lvl],
-               "kernels": kernels}, open(os.path.join(OUT, TAG + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+               "launches_per_pass": 1, "kernels": kernels}, open(os.path.join(OUT, TAG + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(open(os.path.join(OUT, TAG + "_kernel_stats.txt")).read())
-    print(json.dumps({k: {x: kernels[k].get(x) for x in ("hbm_bytes", "hbm_GBps", "lds_bank_conflict_rate", "valu_wave_instr_per_input_byte", "avg_us_kernel_trace")} for k in ("k_match2", "k_sort", "k_adv", "k_emit", "k_seg_exit", "k_pack") if k in kernels}, indent=1))
+    print(json.dumps({k: {x: kernels[k].get(x) for x in ("hbm_bytes", "hbm_GBps", "lds_bank_conflict_rate", "valu_wave_instr_per_input_byte", "avg_us_kernel_trace")} for k in ("k_match3", "k_match2", "k_sort", "k_adv", "k_emit", "k_seg_exit", "k_pack") if k in kernels}, indent=1))
 
 
 main()
