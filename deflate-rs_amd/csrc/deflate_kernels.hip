@@ -979,18 +979,15 @@ __global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ i
 // window, entries left) once per group instead of once per step.  The table is 2 B per position of the
 // previous and the own epoch: 131.6 KB, one workgroup of 16 waves per CU (k_match2: two of them at 64 KB).
 // ---------------------------------------------------------------------------------------------
-#ifndef MI355_M3_GROUPS
-#define MI355_M3_GROUPS 3
-#endif
 constexpr uint32_t M3T = 1024;
 constexpr uint32_t M3_PAIRS = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16: pairs in the table (= bytes staged)
-static_assert(MI355_M3_GROUPS >= 2 && MI355_M3_GROUPS <= 4, "two to four groups of four steps");
 
 struct PairWin {
     const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array (entries are 2 * position)
     uint32_t tbase;      // LDS address of T[0]
     typedef __attribute__((address_space(3))) const uint16_t* lds_u16;
-    __device__ uint32_t pair_at(uint32_t a) const { return *(lds_u16)a; }
+    enum : uint32_t { SH = 1 };
+    __device__ uint32_t key_at(uint32_t a) const { return *(lds_u16)a; }
     // 16 bytes from position pos on: the 40 aligned table bytes that hold T[pos & ~3 ...] are twenty pairs, every
     // other one of them -- the low half of each dword -- new bytes; five 8-byte reads (the 64-bank form), the
     // halves packed by byte selects, then the shift by pos & 3
@@ -1025,74 +1022,218 @@ struct PairWin {
     __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
 };
 
-// A block of MI355_M3_GROUPS groups of four chain steps (stages.h swg_group_ref) for the lanes of `walk`.  Per
-// group: the four entries of one 8-byte load become four probe addresses (16-bit operand selects of the
-// load's registers, fixed v56..v59), the four two-byte reads are issued back to back, and each answer shrinks
-// EXEC when it matches the lane's probe; then the window test on the last address and "entries left".  A lane
-// that leaves keeps a0..a3 / t0..t3 of its last group, offb already a group further: the service finds out
-// where it stopped.  The next group's entries are loaded while this one's answers arrive.
-#define M3_GROUP(LO, HI, MID)                                                                                         \
-    "v_add_u32_sdwa %[a0], " HI ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"      \
-    "v_add_u32_sdwa %[a1], " HI ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"      \
-    "v_add_u32_sdwa %[a2], " LO ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"      \
-    "v_add_u32_sdwa %[a3], " LO ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"      \
-    "ds_read_u16 %[t0], %[a0]\n\t"                                                                                    \
-    "ds_read_u16 %[t1], %[a1]\n\t"                                                                                    \
-    "ds_read_u16 %[t2], %[a2]\n\t"                                                                                    \
-    "ds_read_u16 %[t3], %[a3]\n\t"                                                                                    \
-    "v_add_u32_e32 %[offb], -8, %[offb]\n\t"                                                                          \
-    MID                                                                                                               \
-    "s_waitcnt lgkmcnt(3)\n\t"                                                                                        \
-    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"                                                                      \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                                                        \
-    "v_cmpx_ne_u32_e32 vcc, %[t1], %[probe]\n\t"                                                                      \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                                                        \
-    "v_cmpx_ne_u32_e32 vcc, %[t2], %[probe]\n\t"                                                                      \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                        \
-    "v_cmpx_ne_u32_e32 vcc, %[t3], %[probe]\n\t"                                                                      \
-    "v_cmpx_ge_u32_e32 vcc, %[a3], %[lowa]\n\t"                                                                       \
-    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"                                                                     \
-    "s_cbranch_execz .Lm3_end%=\n\t"
+// A block of chain steps (stages.h swg_group_ref) for the lanes of `walk`: two groups of eight steps (SHAPE 8) or
+// three groups of four (SHAPE 4).  Per group: the entries of one 16- / 8-byte load become probe addresses (16-bit
+// operand selects of the load's registers, fixed v56..v63), the table reads (RD: ds_read_u16 of the pair table,
+// ds_read_u8 of the pair-hash table) are issued back to back, and each answer shrinks EXEC when it equals the
+// lane's probe key; then the window test on the last address and "entries left".  A lane that leaves keeps a / t
+// of its last group, offb already a group further: the service finds out where it stopped.
+#define MS_ADD(A, REG, HALF) "v_add_u32_sdwa %[" A "], " REG ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t"
+#define MS_CMP(N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" T "], %[probe]\n\t"
+#define MS_TAIL(ALAST)                                 \
+    "v_cmpx_ge_u32_e32 vcc, %[" ALAST "], %[lowa]\n\t" \
+    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"      \
+    "s_cbranch_execz .Lms_end%=\n\t"
+#define MS_G4(RD, LO, HI, MID)                                                                             \
+    MS_ADD("a0", HI, "WORD_1") MS_ADD("a1", HI, "WORD_0") MS_ADD("a2", LO, "WORD_1") MS_ADD("a3", LO, "WORD_0") \
+    RD " %[t0], %[a0]\n\t" RD " %[t1], %[a1]\n\t" RD " %[t2], %[a2]\n\t" RD " %[t3], %[a3]\n\t"             \
+    "v_add_u32_e32 %[offb], -8, %[offb]\n\t" MID                                                           \
+    MS_CMP("3", "t0") MS_CMP("2", "t1") MS_CMP("1", "t2") MS_CMP("0", "t3") MS_TAIL("a3")
+#define MS_G8(RD, R0, R1, R2, R3)                                                                          \
+    MS_ADD("a0", R3, "WORD_1") MS_ADD("a1", R3, "WORD_0") MS_ADD("a2", R2, "WORD_1") MS_ADD("a3", R2, "WORD_0") \
+    MS_ADD("a4", R1, "WORD_1") MS_ADD("a5", R1, "WORD_0") MS_ADD("a6", R0, "WORD_1") MS_ADD("a7", R0, "WORD_0") \
+    RD " %[t0], %[a0]\n\t" RD " %[t1], %[a1]\n\t" RD " %[t2], %[a2]\n\t" RD " %[t3], %[a3]\n\t"             \
+    RD " %[t4], %[a4]\n\t" RD " %[t5], %[a5]\n\t" RD " %[t6], %[a6]\n\t" RD " %[t7], %[a7]\n\t"             \
+    "v_add_u32_e32 %[offb], -16, %[offb]\n\t"                                                              \
+    MS_CMP("7", "t0") MS_CMP("6", "t1") MS_CMP("5", "t2") MS_CMP("4", "t3")                                \
+    MS_CMP("3", "t4") MS_CMP("2", "t5") MS_CMP("1", "t6") MS_CMP("0", "t7") MS_TAIL("a7")
+// two groups of eight: entries off-7 .. off and off-15 .. off-8, both loaded at the start
+#define MS_LOADS8                                                        \
+    "global_load_dwordx4 v[56:59], %[offb], %[sb] offset:-14\n\t"        \
+    "global_load_dwordx4 v[60:63], %[offb], %[sb] offset:-30\n\t"
+#define MS_BODY8(RD)                                                     \
+    MS_LOADS8                                                            \
+    "s_waitcnt vmcnt(1)\n\t"                                             \
+    MS_G8(RD, "v56", "v57", "v58", "v59")                                \
+    "s_waitcnt vmcnt(0)\n\t"                                             \
+    MS_G8(RD, "v60", "v61", "v62", "v63")
+// three groups of four: the third group's entries are loaded while the first one's answers arrive (offb has
+// moved on by one group then)
+#define MS_BODY4(RD)                                                     \
+    "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"         \
+    "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"        \
+    "s_waitcnt vmcnt(1)\n\t"                                             \
+    MS_G4(RD, "v56", "v57", "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t") \
+    "s_waitcnt vmcnt(1)\n\t"                                             \
+    MS_G4(RD, "v58", "v59", "")                                          \
+    "s_waitcnt vmcnt(0)\n\t"                                             \
+    MS_G4(RD, "v56", "v57", "")
+#define MS_STEPS(NAME, BODY, OPS8, ...)                                                                                       \
+    template <bool HAS_Q>                                                                                                     \
+    __device__ __forceinline__ uint64_t NAME(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {                             \
+        uint64_t save, still;                                                                                                 \
+        asm volatile("s_mov_b64 %[save], exec\n\t"                                                                            \
+                     "s_mov_b64 exec, %[walk]\n\t" BODY ".Lms_end%=:\n\t"                                                     \
+                     "s_waitcnt vmcnt(0)\n\t"                                                                                 \
+                     "s_mov_b64 %[still], exec\n\t"                                                                           \
+                     "s_mov_b64 exec, %[save]\n\t"                                                                            \
+                     : [offb] "+v"(s.offb), [a0] "+v"(s.a0), [a1] "+v"(s.a1), [a2] "+v"(s.a2), [a3] "+v"(s.a3), [t0] "+v"(s.t0), \
+                       [t1] "+v"(s.t1), [t2] "+v"(s.t2), [t3] "+v"(s.t3), OPS8 [save] "=&s"(save), [still] "=&s"(still)       \
+                     : [bb] "v"(s.bb2), [lowa] "v"(s.lowa2), [probe] "v"(s.probe), [endb] "v"(s.endb), [sb] "s"(sb8),         \
+                       [walk] "s"(walk)                                                                                       \
+                     : "vcc", "memory", "v56", "v57", "v58", "v59", ##__VA_ARGS__);                                           \
+        return still;                                                                                                         \
+    }
+#define MS_OPS8                                                                                                                   \
+    [a4] "+v"(s.a4), [a5] "+v"(s.a5), [a6] "+v"(s.a6), [a7] "+v"(s.a7), [t4] "+v"(s.t4), [t5] "+v"(s.t5), [t6] "+v"(s.t6), [t7] "+v"(s.t7),
+#define MS_OPS4
+MS_STEPS(ms_steps_pair8, MS_BODY8("ds_read_u16"), MS_OPS8, "v60", "v61", "v62", "v63")
+MS_STEPS(ms_steps_pair4, MS_BODY4("ds_read_u16"), MS_OPS4)
+MS_STEPS(ms_steps_key8, MS_BODY8("ds_read_u8"), MS_OPS8, "v60", "v61", "v62", "v63")
+MS_STEPS(ms_steps_key4, MS_BODY4("ds_read_u8"), MS_OPS4)
+
+#ifndef MI355_M3_W
+#define MI355_M3_W 8
+#endif
+#ifndef MI355_M3_DUAL
+#define MI355_M3_DUAL 1
+#endif
+static_assert(!MI355_M3_DUAL || MI355_M3_W == 8, "two fibres walk in groups of eight");
+#ifndef MI355_M4_W
+#define MI355_M4_W 4
+#endif
+static_assert((MI355_M3_W == 4 || MI355_M3_W == 8) && (MI355_M4_W == 4 || MI355_M4_W == 8), "groups of four or eight steps");
+
+// Where the lanes of `dropped` stopped in their last group of W steps: at the first probe that equals their key
+// (the compares of the step block shrank EXEC there) -> *any, the probe's address and how far offb is past its
+// entry; the other lanes left at the end of the group.
+// (probe keys and addresses BY VALUE: selects among the fields of a struct behind a reference become a load through a
+// selected pointer, and the struct then lives in scratch memory)
+struct MsGroup {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, a0, a1, a2, a3, a4, a5, a6, a7, probe;
+};
+template <int W>
+__device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, uint32_t* asel_out, uint32_t* back_out) {
+    const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe);
+    const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & ~e0m;
+    const uint64_t e2m = __builtin_amdgcn_ballot_w64(st.t2 == st.probe) & ~(e0m | e1m);
+    uint64_t any = e0m | e1m | e2m;
+    const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & ~any;
+    any |= e3m;
+    uint32_t asel, back;
+    if (W == 8) {
+        const uint64_t e4m = __builtin_amdgcn_ballot_w64(st.t4 == st.probe) & ~any;
+        any |= e4m;
+        const uint64_t e5m = __builtin_amdgcn_ballot_w64(st.t5 == st.probe) & ~any;
+        any |= e5m;
+        const uint64_t e6m = __builtin_amdgcn_ballot_w64(st.t6 == st.probe) & ~any;
+        any |= e6m;
+        const uint64_t e7m = __builtin_amdgcn_ballot_w64(st.t7 == st.probe) & ~any;
+        any |= e7m;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e7m) ? st.a7 : st.a0;
+        back = __builtin_amdgcn_inverse_ballot_w64(e7m) ? 2u : 16u;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e6m) ? st.a6 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e6m) ? 4u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e5m) ? st.a5 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e5m) ? 6u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e4m) ? st.a4 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e4m) ? 8u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 10u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 12u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 14u : back;
+    } else {
+        asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : st.a0;
+        back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 2u : 8u;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 4u : back;
+        asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
+        back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 6u : back;
+    }
+    *any_out = any;
+    *asel_out = asel;
+    *back_out = back;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match3 with two batches per wave (MI355_M3_DUAL, the default): the pair table leaves one workgroup of 16
+// waves per CU -- four per SIMD, with more than half of the 128 vector registers each may use idle -- and at
+// four waves the kernel is bound by the latency of its dependent steps (table read -> compare -> next group;
+// entry load -> first group), not by any unit: vector ALU 72 %, LDS 50 %, TA 52 % busy.  So a wave walks TWO
+// batches of 64 positions at once, fibre x and fibre y, each with its own SwG state: the step block issues the
+// entry loads and the eight table reads of both fibres before it looks at the first answer (16 reads in flight
+// per wave), the services and set-ups of the two follow each other.  Twice the work per latency.
+// ---------------------------------------------------------------------------------------------
+#define MF_ADD(F, A, REG, HALF) \
+    "v_add_u32_sdwa %[" F A "], " REG ", %[" F "bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t"
+#define MF_CMP(F, N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
+#define MF_ISSUE8(F, R0, R1, R2, R3)                                                                                 \
+    MF_ADD(F, "a0", R3, "WORD_1") MF_ADD(F, "a1", R3, "WORD_0") MF_ADD(F, "a2", R2, "WORD_1") MF_ADD(F, "a3", R2, "WORD_0") \
+    MF_ADD(F, "a4", R1, "WORD_1") MF_ADD(F, "a5", R1, "WORD_0") MF_ADD(F, "a6", R0, "WORD_1") MF_ADD(F, "a7", R0, "WORD_0") \
+    "ds_read_u16 %[" F "t0], %[" F "a0]\n\tds_read_u16 %[" F "t1], %[" F "a1]\n\tds_read_u16 %[" F "t2], %[" F "a2]\n\t"    \
+    "ds_read_u16 %[" F "t3], %[" F "a3]\n\tds_read_u16 %[" F "t4], %[" F "a4]\n\tds_read_u16 %[" F "t5], %[" F "a5]\n\t"    \
+    "ds_read_u16 %[" F "t6], %[" F "a6]\n\tds_read_u16 %[" F "t7], %[" F "a7]\n\t"                                       \
+    "v_add_u32_e32 %[" F "offb], -16, %[" F "offb]\n\t"
+// the eight answers of a fibre in turn, then window and entries left; N0 = reads of the other fibre still behind them
+#define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
+    MF_CMP(F, N7, "t0") MF_CMP(F, N6, "t1") MF_CMP(F, N5, "t2") MF_CMP(F, N4, "t3")                                \
+    MF_CMP(F, N3, "t4") MF_CMP(F, N2, "t5") MF_CMP(F, N1, "t6") MF_CMP(F, N0, "t7")                                \
+    "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
+    "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+#define MF_OPS(F, S)                                                                                                        \
+    [F##offb] "+v"(S.offb), [F##a0] "+v"(S.a0), [F##a1] "+v"(S.a1), [F##a2] "+v"(S.a2), [F##a3] "+v"(S.a3), [F##a4] "+v"(S.a4), \
+    [F##a5] "+v"(S.a5), [F##a6] "+v"(S.a6), [F##a7] "+v"(S.a7), [F##t0] "+v"(S.t0), [F##t1] "+v"(S.t1), [F##t2] "+v"(S.t2), \
+    [F##t3] "+v"(S.t3), [F##t4] "+v"(S.t4), [F##t5] "+v"(S.t5), [F##t6] "+v"(S.t6), [F##t7] "+v"(S.t7)
+#define MF_INS(F, S) [F##bb] "v"(S.bb2), [F##lowa] "v"(S.lowa2), [F##probe] "v"(S.probe), [F##endb] "v"(S.endb)
 
 template <bool HAS_Q>
-__device__ __forceinline__ uint64_t m3_steps(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {
-    uint64_t save, still;
+__device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_t* sb8, uint64_t walkx, uint64_t walky,
+                                              uint64_t* stillx, uint64_t* stilly) {
+    uint64_t save, cx, cy;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[walk]\n\t"
-        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"   // entries off-3 .. off
-        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"  // entries off-7 .. off-4
+        "s_mov_b64 exec, %[wx]\n\t"
+        "global_load_dwordx4 v[56:59], %[xoffb], %[sb] offset:-14\n\t"  // x: entries off-7 .. off
+        "global_load_dwordx4 v[60:63], %[xoffb], %[sb] offset:-30\n\t"  //    off-15 .. off-8
+        "s_mov_b64 exec, %[wy]\n\t"
+        "global_load_dwordx4 v[64:67], %[yoffb], %[sb] offset:-14\n\t"
+        "global_load_dwordx4 v[68:71], %[yoffb], %[sb] offset:-30\n\t"
+        "s_mov_b64 exec, %[wx]\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        MF_ISSUE8("x", "v56", "v57", "v58", "v59")
+        "s_mov_b64 exec, %[wy]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
-#if MI355_M3_GROUPS >= 3
-        M3_GROUP("v56", "v57", "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t")  // (offb has moved on by four entries)
-        "s_waitcnt vmcnt(1)\n\t"
-#else
-        M3_GROUP("v56", "v57", "")
+        MF_ISSUE8("y", "v64", "v65", "v66", "v67")
+        "s_mov_b64 exec, %[wx]\n\t"
+        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8")
+        "s_mov_b64 %[cx], exec\n\t"
+        "s_mov_b64 exec, %[wy]\n\t"
+        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0")
+        "s_mov_b64 %[cy], exec\n\t"
+        "s_or_b64 vcc, %[cx], %[cy]\n\t"
+        "s_cbranch_scc0 .Lmf_end%=\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-#endif
-#if MI355_M3_GROUPS >= 4
-        M3_GROUP("v58", "v59", "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t")
-        "s_waitcnt vmcnt(1)\n\t"
-#else
-        M3_GROUP("v58", "v59", "")
+        "s_mov_b64 exec, %[cx]\n\t"
+        MF_ISSUE8("x", "v60", "v61", "v62", "v63")
+        "s_mov_b64 exec, %[cy]\n\t"
+        MF_ISSUE8("y", "v68", "v69", "v70", "v71")
+        "s_mov_b64 exec, %[cx]\n\t"
+        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8")
+        "s_mov_b64 %[cx], exec\n\t"
+        "s_mov_b64 exec, %[cy]\n\t"
+        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0")
+        "s_mov_b64 %[cy], exec\n\t"
+        ".Lmf_end%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-#endif
-#if MI355_M3_GROUPS >= 3
-        M3_GROUP("v56", "v57", "")
-#endif
-#if MI355_M3_GROUPS >= 4
-        "s_waitcnt vmcnt(0)\n\t"
-        M3_GROUP("v58", "v59", "")
-#endif
-        ".Lm3_end%=:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 %[still], exec\n\t"
         "s_mov_b64 exec, %[save]\n\t"
-        : [offb] "+v"(s.offb), [a0] "+v"(s.a0), [a1] "+v"(s.a1), [a2] "+v"(s.a2), [a3] "+v"(s.a3), [t0] "+v"(s.t0),
-          [t1] "+v"(s.t1), [t2] "+v"(s.t2), [t3] "+v"(s.t3), [save] "=&s"(save), [still] "=&s"(still)
-        : [bb] "v"(s.bb2), [lowa] "v"(s.lowa2), [probe] "v"(s.probe), [endb] "v"(s.endb), [sb] "s"(sb8), [walk] "s"(walk)
-        : "vcc", "memory", "v56", "v57", "v58", "v59");
-    return still;
+        : MF_OPS(x, x), MF_OPS(y, y), [save] "=&s"(save), [cx] "=&s"(cx), [cy] "=&s"(cy)
+        : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky)
+        : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",
+          "v70", "v71");
+    *stillx = cx;
+    *stilly = cy;
 }
 
 template <bool HAS_Q>
@@ -1157,15 +1298,10 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     M2_T0
-    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= b_hi) break;
+    // set a fibre up for batch b (all lanes call it: the lane masks it sets must be ballots of the whole wave)
+    auto set_up = [&](SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out) -> bool {
         const uint32_t j = b * 64 + lane;
-        const bool valid = j < J;
-        SwG<HAS_Q> st;
+        const bool valid = have && j < J;
         uint32_t srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
         if (valid) {
             srel = (uint32_t)own[j] >> 1;
@@ -1180,34 +1316,306 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             nrel = lim(prel);
         }
+        (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
+        st.done = ~st.walk;
+        *srel_out = srel;
+        return valid;
+    };
+    // settle the lanes of a fibre that left the last block
+    auto settle = [&](SwG<HAS_Q>& st, uint64_t dropped) {
+        uint64_t any;
+        uint32_t asel, back;
+        ms_decode<MI355_M3_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
+                                      st.a6, st.a7, st.probe},
+                              &any, &asel, &back);
+        // a lane that used up its last segment without a hit has its result: only hits and the move to the
+        // previous epoch's bucket need the service
+        if ((any & dropped) | (dropped & st.has2)) {
+            M2_CNT(2, 1)
+            M2_CNT(3, __popcll(dropped))
+            swg_service(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
+        }
+    };
+#if MI355_M3_DUAL
+    uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 2u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= b_hi) break;
+        SwG<HAS_Q> sx, sy;
+        uint32_t srx, sry;
+        const bool vx = set_up(sx, b, true, &srx);
+        const bool vy = set_up(sy, b + 1, b + 1 < b_hi, &sry);
+        M2_CNT(0, 2)
+        M2_T(8)
+#ifndef MI355_M3_NOSTORE
+        // (the results of the pair before go out here, behind this pair's set-up loads: see k_match2)
+        if (pxat != ~0u) {
+            M[E + pxat] = pxm;
+            if (HAS_Q) Mq[E + pxat] = pxq;
+        }
+        if (pyat != ~0u) {
+            M[E + pyat] = pym;
+            if (HAS_Q) Mq[E + pyat] = pyq;
+        }
+#endif
+        // the first candidate of every lane goes straight to the service
+        uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
+        for (;;) {
+            if (dx) settle(sx, dx);
+            if (dy) settle(sy, dy);
+            M2_T(9)
+            const uint64_t wx = sx.walk, wy = sy.walk;
+            if ((wx | wy) == 0) break;
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(wx) + __popcll(wy))
+            uint64_t cx, cy;
+            ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
+            M2_T(12)
+            sx.walk = cx;
+            sy.walk = cy;
+            dx = wx & ~cx;
+            dy = wy & ~cy;
+        }
+        swg_result(sx, &pxm, &pxq);
+        swg_result(sy, &pym, &pyq);
+        pxat = vx ? srx : ~0u;
+        pyat = vy ? sry : ~0u;
+        M2_T(13)
+    }
+#ifndef MI355_M3_NOSTORE
+    if (pxat != ~0u) {
+        M[E + pxat] = pxm;
+        if (HAS_Q) Mq[E + pxat] = pxq;
+    }
+    if (pyat != ~0u) {
+        M[E + pyat] = pym;
+        if (HAS_Q) Mq[E + pyat] = pyq;
+    }
+#endif
+#else
+    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= b_hi) break;
+        SwG<HAS_Q> st;
+        uint32_t srel;
+        const bool valid = set_up(st, b, true, &srel);
+        M2_CNT(0, 1)
+        M2_T(8)
+#ifndef MI355_M3_NOSTORE
+        if (pend_at != ~0u) {  // (the results of the batch before, behind this batch's set-up loads: see k_match2)
+            M[E + pend_at] = pend_m;
+            if (HAS_Q) Mq[E + pend_at] = pend_mq;
+        }
+#endif
+        uint64_t dropped = swg_first(st, win, (uint32_t)MI355_M3_W);  // the first candidate goes straight to the service
+        for (;;) {
+            if (dropped) settle(st, dropped);
+            M2_T(9)
+            const uint64_t walk = st.walk;
+            if (walk == 0) break;
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(walk))
+            const uint64_t still = MI355_M3_W == 8 ? ms_steps_pair8(st, sbase - 4, walk) : ms_steps_pair4(st, sbase - 4, walk);
+            M2_T(12)
+            st.walk = still;
+            dropped = walk & ~still;
+        }
+        swg_result(st, &pend_m, &pend_mq);
+        pend_at = valid ? srel : ~0u;
+        M2_T(13)
+    }
+#ifndef MI355_M3_NOSTORE
+    if (pend_at != ~0u) {
+        M[E + pend_at] = pend_m;
+        if (HAS_Q) Mq[E + pend_at] = pend_mq;
+    }
+#endif
+#endif
+#ifdef MI355_MATCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match4: the walk of k_match3 (stages.h SwG) over a table that fits the CU twice.  The probe never needs the
+// two bytes themselves, only something that is equal whenever they are: LDS holds ONE byte per position, an
+// 8-bit key of the pair (byte k, byte k+1) (stages.h pair_key8) -- 64 KB for the previous and the own epoch,
+// so two workgroups (8 waves per SIMD) share a CU again, as in k_match2, while a visit stays one LDS read and
+// two vector instructions.  A candidate whose key matches by chance (1 in 256) is compared and dropped like any
+// other the reference's probe passes in vain.  The bytes of a compare -- 16 of the candidate, once per hit; 16
+// of the position, once at set-up -- come from global memory (the input is resident in L2 / the Infinity
+// Cache), and the lane's next probe key is read from the table at its own position + best - 1.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t M4T = 1024;
+constexpr uint32_t M4_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
+
+struct KeyWin {
+    enum : uint32_t { SH = 0 };
+    const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array
+    uint32_t tbase;      // LDS address of the key of window position 0
+    const uint8_t* wp;   // global: the window's first byte
+    uint32_t nw;         // bytes of input from wp on
+    typedef __attribute__((address_space(3))) const uint8_t* lds_u8;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __device__ uint32_t key_at(uint32_t a) const { return *(lds_u8)a; }
+    __device__ void load16(uint32_t pos, uint32_t* q) const {
+        if (nw >= 16 && pos <= nw - 16) {  // (the hardware takes a 16-byte load at any byte address; `pos` may be anything)
+            u32x4 v;
+            __builtin_memcpy(&v, wp + pos, 16);
+            q[0] = v.x;
+            q[1] = v.y;
+            q[2] = v.z;
+            q[3] = v.w;
+        } else {  // the last bytes of the input, or an address that means nothing (a lane that has nothing to compare)
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // (named: a loop over q[] would put it in scratch memory)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (pos + b < nw) r0 |= (uint32_t)wp[pos + b] << (8 * b);
+                if (pos + 4 + b < nw) r1 |= (uint32_t)wp[pos + 4 + b] << (8 * b);
+                if (pos + 8 + b < nw) r2 |= (uint32_t)wp[pos + 8 + b] << (8 * b);
+                if (pos + 12 + b < nw) r3 |= (uint32_t)wp[pos + 12 + b] << (8 * b);
+            }
+            q[0] = r0;
+            q[1] = r1;
+            q[2] = r2;
+            q[3] = r3;
+        }
+    }
+    __device__ uint32_t load32(uint32_t pos) const {
+        uint32_t v = 0;
+        if (nw >= 4 && pos <= nw - 4) {
+            __builtin_memcpy(&v, wp + pos, 4);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (pos + b < nw) v |= (uint32_t)wp[pos + b] << (8 * b);
+        }
+        return v;
+    }
+    __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
+};
+
+template <bool HAS_Q>
+__global__ __launch_bounds__(M4T, 8) void k_match4(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                   const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                   uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
+                                                   SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split) {
+    __shared__ __attribute__((aligned(16))) uint4 s_K[M4_BYTES / 16];  // key of (byte k, byte k+1), k from the window's start
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
+    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
+    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
+    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
+    // stage the keys: 16 bytes and the byte behind them make 16 keys = one 16-byte store
+    for (uint32_t w = tid; w < wbytes / 16; w += M4T) {
+        const uint64_t g = wbase + 16ull * w;
+        uint32_t t[5] = {0, 0, 0, 0, 0};
+        if (in_aligned16 && g + 20 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(in + g);
+            t[0] = v.x;
+            t[1] = v.y;
+            t[2] = v.z;
+            t[3] = v.w;
+            t[4] = *reinterpret_cast<const uint32_t*>(in + g + 16);
+        } else {
+            for (int b = 0; b < 17; b++)
+                if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // pair_key8 on four pairs at once: x ^ (y << 3) ^ (y >> 5) per byte, y = the bytes one place on
+            const uint32_t x = t[k], y = __builtin_amdgcn_alignbyte(t[k + 1], t[k], 1);
+            o[k] = x ^ ((y << 3) & 0xf8f8f8f8u) ^ ((y >> 5) & 0x07070707u);
+        }
+        s_K[w] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    const uint32_t J = epoch_active(n, E);
+    const uint32_t nbat = (J + 63) / 64;
+    const uint32_t b_lo = (uint32_t)((uint64_t)nbat * part / split), b_hi = (uint32_t)((uint64_t)nbat * (part + 1) / split);
+    if (tid == 0) s_next = b_lo;
+    if (part == 0 && tid < 2) {  // the positions without a hash byte (the last two of the input) are never searched
+        const uint64_t p = E + J + tid;
+        if (p < n && p < E + WINDOW_SIZE) {
+            M[p] = 0;
+            if (HAS_Q) Mq[p] = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_K;
+    const uint32_t bias = (uint32_t)(E - wbase);  // position of the own epoch's first byte in the window
+    const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;  // (see k_match3)
+    KeyWin win{sbase, tbase, in + wbase, (uint32_t)(n - wbase)};
+    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
+    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
+    const uint16_t* Bprev = Bown - BSTRIDE;
+    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
+#ifdef MI355_MATCH_STATS
+    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    M2_T0
+    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= b_hi) break;
+        const uint32_t j = b * 64 + lane;
+        const bool valid = j < J;
+        SwG<HAS_Q> st;
+        uint32_t srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
+        uint32_t hv = 0;
+        if (valid) {
+            srel = own[j];
+            prel = bias + srel;
+            hv = win.load32(prel);
+        }
+        if (valid) {
+            const uint32_t ab = rewarm_ab(ov, E + srel, hv & 0xff, (hv >> 8) & 0xff);
+            const uint32_t h = hash3(ab & 0xff, ab >> 8, (hv >> 16) & 0xff);
+            ob = Bown[h];
+            if (e) {
+                pb0 = Bprev[h];
+                pb1 = Bprev[h + 1];
+            }
+            nrel = lim(prel);
+        }
         // (one call for all lanes: the lane masks it sets must be ballots of the whole wave)
         (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
         st.done = ~st.walk;
         M2_CNT(0, 1)
         M2_T(8)
-        // (the results of the batch before go out here, behind this batch's set-up loads: see k_match2)
-        if (pend_at != ~0u) {
+        if (pend_at != ~0u) {  // (the results of the batch before, behind this batch's set-up loads: see k_match2)
             M[E + pend_at] = pend_m;
             if (HAS_Q) Mq[E + pend_at] = pend_mq;
         }
-        // the first candidate of every lane goes straight to the service
-        uint64_t dropped = swg_first(st, win);
+        uint64_t dropped = swg_first(st, win, (uint32_t)MI355_M4_W);  // the first candidate goes straight to the service
         for (;;) {
             if (dropped) {
-                const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe) & dropped;
-                const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & dropped & ~e0m;
-                const uint64_t e2m = __builtin_amdgcn_ballot_w64(st.t2 == st.probe) & dropped & ~(e0m | e1m);
-                const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & dropped & ~(e0m | e1m | e2m);
-                M2_CNT(2, 1)
-                M2_CNT(3, __popcll(dropped))
-                swg_service(st, win, tbase, checks_q, dropped, e0m, e1m, e2m, e3m, st.a0, st.a1, st.a2, st.a3);
+                uint64_t any;
+                uint32_t asel, back;
+                ms_decode<MI355_M4_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
+                                              st.a6, st.a7, st.probe},
+                                      &any, &asel, &back);
+                if ((any & dropped) | (dropped & st.has2)) {  // (see k_match3)
+                    M2_CNT(2, 1)
+                    M2_CNT(3, __popcll(dropped))
+                    swg_service(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
+                }
                 M2_T(9)
             }
             const uint64_t walk = st.walk;
             if (walk == 0) break;
             M2_CNT(1, 1)
             M2_CNT(7, __popcll(walk))
-            const uint64_t still = m3_steps(st, sbase - 4, walk);
+            const uint64_t still = MI355_M4_W == 8 ? ms_steps_key8(st, sbase - 4, walk) : ms_steps_key4(st, sbase - 4, walk);
             M2_T(12)
             st.walk = still;
             dropped = walk & ~still;

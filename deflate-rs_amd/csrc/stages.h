@@ -140,6 +140,18 @@ MI355_HD uint32_t position_hash(const Bytes& by, uint64_t p, const HashOverride&
     return hash3(ab & 0xff, ab >> 8, by(p + 2));
 }
 
+// index of the lowest set bit, all ones for zero -- which an OR keeps all ones, so that a zero word drops out of
+// a minimum (v_ffbl_b32 does exactly this; __builtin_ffs - 1 costs a compare and a select on top)
+MI355_HD uint32_t first_bit_or_ones(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu;
+#endif
+}
+
 MI355_HD uint32_t ctz32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_ctz(x);
@@ -1006,16 +1018,25 @@ MI355_HD void swl_result(const SwLean<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
 //   * the quarter result of lz77.rs:351-355 is taken when the first hit beyond the quarter budget is
 //     settled (or the final result, when there is none): no run ends there.
 // Coordinates: positions count from the window's first byte (`org` = 0); probe addresses are LDS addresses
-// tbase + 2 * position (tbase = 0 on the host).
+// tbase + (position << W::SH) (tbase = 0 on the host), and the sorted arrays hold position << W::SH.
+// The table need not even hold the pair itself: W::key_at may return any function of the two bytes (k_match4
+// keeps an 8-bit hash of every pair, one byte per position, and fetches the bytes of a compare from global
+// memory) -- two positions whose pairs are equal have equal keys, so no candidate the probe would pass is
+// lost, and one passed in vain is compared and dropped like any other.
+// k_match4's key of a byte pair (any function of the two bytes would do; this one keeps letters apart)
+MI355_HD uint32_t pair_key8(uint32_t x, uint32_t y) { return (x ^ (y << 3) ^ (y >> 5)) & 0xffu; }
+
 template <bool HAS_Q>
 struct SwG {
     uint32_t offb, endb, bb2, lowa2, probe;  // the registers of the step block (offb = 2 * index + 8 of the next entry)
-    uint32_t a0, a1, a2, a3, t0, t1, t2, t3;  // probe addresses and probe bytes of the last group (named: an array
-                                             // selected by lane masks ends up in scratch memory on the GPU)
+    // probe addresses and probe bytes of the last group -- of four or of eight steps (named: an array selected by
+    // lane masks ends up in scratch memory on the GPU)
+    uint32_t a0, a1, a2, a3, a4, a5, a6, a7, t0, t1, t2, t3, t4, t5, t6, t7;
     uint32_t prel, maxlen, p16[4], bm1, bestd, low;
     uint32_t offb2, endb2;                   // the segment in the previous epoch's bucket (none: offb2 < endb2)
     uint32_t seg0, vbase, mq;                // HAS_Q: offset of the segment's first entry, candidates of the segment before
     lane_flag walk, done, in_prev, hq;
+    lane_flag has2;  // a segment in the previous epoch's bucket is still to come
 };
 
 // Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the previous
@@ -1033,8 +1054,8 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.vbase = 0;
     s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
     s.done = lf_of(false);
-    s.a0 = s.a1 = s.a2 = s.a3 = tbase;
-    s.t0 = s.t1 = s.t2 = s.t3 = 0;
+    s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = s.a5 = s.a6 = s.a7 = tbase;
+    s.t0 = s.t1 = s.t2 = s.t3 = s.t4 = s.t5 = s.t6 = s.t7 = 0;
     const bool search = prel + 2 < nrel && checks > 0;
     const uint32_t left = nrel - prel;
     s.maxlen = search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u;
@@ -1048,79 +1069,79 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.offb = own ? 2 * (SW_OWN + j - 1) + 8 : s.offb2;
     s.endb = own ? s.offb + 2 - 2 * n1 : s.endb2;
     s.in_prev = lf_of(!own);
+    s.has2 = lf_of(own && n2 > 0);
     s.seg0 = s.offb;
-    s.bb2 = tbase + 2 * (own ? bias : 0u);
-    s.lowa2 = tbase + 2 * s.low;
+    s.bb2 = tbase + ((own ? bias : 0u) << W::SH);
+    s.lowa2 = tbase + (s.low << W::SH);
     w.load16(prel, s.p16);
-    s.probe = s.p16[0] & 0xffffu;
+    s.probe = w.key_at(tbase + (prel << W::SH));
     s.walk = lf_of(search && n1 + n2 > 0);
     return search;
 }
 
 // The first candidate of every lane that walks is settled without a step: same-bucket entries nearly always
 // share the first two bytes, so the lanes would all leave their first group at its first probe.  Pretends
-// that group: a[0] / t[0] of a hit, offb a group further.  Returns the lanes concerned (the d0 of swg_service).
+// that group: a0 / t0 of a hit, offb a group (of `width` steps) further.  Returns the lanes concerned.
 template <bool HAS_Q, class W>
-MI355_HD lane_flag swg_first(SwG<HAS_Q>& s, const W& w) {
+MI355_HD lane_flag swg_first(SwG<HAS_Q>& s, const W& w, uint32_t width) {
     const lane_flag st = s.walk;
     uint32_t e2 = 0;
     if (lf_me(st)) e2 = w.sidx((uint32_t)((int32_t)(s.offb - 8) >> 1));
     s.a0 = lf_me(st) ? e2 + s.bb2 : s.a0;
     s.t0 = lf_me(st) ? s.probe : s.t0;
-    s.offb -= lf_me(st) ? 8u : 0u;
+    s.offb -= lf_me(st) ? 2 * width : 0u;
     s.walk = lf_of(false);
     return st;
 }
 
-// One group of four steps of a walking lane (host twin of the GPU's step block): the four entries from offb
-// downwards, their probe reads, then the tests in the GPU's order -- probe 0..3 (the first hit ends it:
-// `d` = its number), window of the last, entries left.  A lane that leaves keeps a[] / t[] of this group.
+// One group of `width` (four or eight) steps of a walking lane (host twin of the GPU's step block): the entries
+// from offb downwards, their probe reads, then the tests in the GPU's order -- the probes in turn (the first hit
+// ends it: `d` = its number), window of the last, entries left.  A lane that leaves keeps a / t of this group.
 template <bool HAS_Q, class W>
-MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d) {
+MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d, uint32_t width) {
     *d = -1;
     if (!lf_me(s.walk)) return;
     const int32_t idx = (int32_t)(s.offb - 8) >> 1;
-    s.a0 = w.sidx((uint32_t)idx) + s.bb2;
-    s.a1 = w.sidx((uint32_t)(idx - 1)) + s.bb2;
-    s.a2 = w.sidx((uint32_t)(idx - 2)) + s.bb2;
-    s.a3 = w.sidx((uint32_t)(idx - 3)) + s.bb2;
-    s.t0 = w.pair_at(s.a0);
-    s.t1 = w.pair_at(s.a1);
-    s.t2 = w.pair_at(s.a2);
-    s.t3 = w.pair_at(s.a3);
-    s.offb -= 8;
-    const int hit = s.t0 == s.probe ? 0 : (s.t1 == s.probe ? 1 : (s.t2 == s.probe ? 2 : (s.t3 == s.probe ? 3 : -1)));
-    if (hit >= 0) {
-        *d = hit;
-        s.walk = lf_of(false);
-        return;
+    uint32_t a[8], t[8];
+    for (uint32_t i = 0; i < width; i++) {
+        a[i] = w.sidx((uint32_t)(idx - (int32_t)i)) + s.bb2;
+        t[i] = w.key_at(a[i]);
     }
-    if (s.a3 < s.lowa2 || (int32_t)s.offb < (int32_t)s.endb) s.walk = lf_of(false);
+    for (uint32_t i = width; i < 8; i++) {
+        a[i] = s.a7;
+        t[i] = s.t7;
+    }
+    s.a0 = a[0]; s.a1 = a[1]; s.a2 = a[2]; s.a3 = a[3]; s.a4 = a[4]; s.a5 = a[5]; s.a6 = a[6]; s.a7 = a[7];
+    s.t0 = t[0]; s.t1 = t[1]; s.t2 = t[2]; s.t3 = t[3]; s.t4 = t[4]; s.t5 = t[5]; s.t6 = t[6]; s.t7 = t[7];
+    s.offb -= 2 * width;
+    for (uint32_t i = 0; i < width; i++)
+        if (t[i] == s.probe) {
+            *d = (int)i;
+            s.walk = lf_of(false);
+            return;
+        }
+    if (a[width - 1] < s.lowa2 || (int32_t)s.offb < (int32_t)s.endb) s.walk = lf_of(false);
 }
 
-// Settle the lanes that left the last block (`dropped`; d0..d3 = those that left at the probe of step 0..3 of
-// their last group, the others left at its end).  Straight-line selects; only a match longer than 16 bytes loops.
+// Settle the lanes that left the last block (`dropped`).  `dany` = those that left at a probe, `asel` = that
+// probe's address, `ho` = the offset of its entry (the caller picks them from a / t and offb: which step it was
+// is read off the probe bytes; the others left at the end of their group).  Straight-line selects; only a match
+// longer than 16 bytes loops.
 template <bool HAS_Q, class W>
-MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag d0,
-                          lane_flag d1, lane_flag d2, lane_flag d3, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
-    // (a0..a3 = s.a0..s.a3, by value: a select among neighbouring fields of a struct behind a reference is turned
-    // into a load through a selected pointer, and the whole struct then lives in scratch memory on the GPU)
-    // which entry: a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of
-    // the window (positions fall along a segment, so the hit's own address tells), is no hit
-    const lane_flag dany = d0 | d1 | d2 | d3;
-    const uint32_t asel = lf_me(d0) ? a0 : (lf_me(d1) ? a1 : (lf_me(d2) ? a2 : a3));
-    const uint32_t back = lf_me(d0) ? 8u : (lf_me(d1) ? 6u : (lf_me(d2) ? 4u : 2u));
-    const uint32_t ho = s.offb + back;  // offset of the entry in question
+MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
+                          uint32_t asel, uint32_t ho) {
+    // a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of the window
+    // (positions fall along a segment, so the hit's own address tells), is no hit
     const lane_flag hit = dany & lf_of((int32_t)ho >= (int32_t)s.endb && asel >= s.lowa2);  // matching.rs:102-106,127,141-143
     lane_flag rend = lf_and_not(dropped, hit);  // the segment is used up, or its next candidate is out of reach
     // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
-    const uint32_t cpos = ((asel - tbase) >> 1) - s.bm1;
+    const uint32_t cpos = ((asel - tbase) >> W::SH) - s.bm1;
     uint32_t q[4];
     w.load16(cpos, q);
-    const uint32_t b0 = (uint32_t)(__builtin_ffs((int)(q[0] ^ s.p16[0])) - 1);
-    const uint32_t b1 = (uint32_t)(__builtin_ffs((int)(q[1] ^ s.p16[1])) - 1) | 32u;
-    const uint32_t b2 = (uint32_t)(__builtin_ffs((int)(q[2] ^ s.p16[2])) - 1) | 64u;
-    const uint32_t b3 = (uint32_t)(__builtin_ffs((int)(q[3] ^ s.p16[3])) - 1) | 96u;
+    const uint32_t b0 = first_bit_or_ones(q[0] ^ s.p16[0]);
+    const uint32_t b1 = first_bit_or_ones(q[1] ^ s.p16[1]) | 32u;
+    const uint32_t b2 = first_bit_or_ones(q[2] ^ s.p16[2]) | 64u;
+    const uint32_t b3 = first_bit_or_ones(q[3] ^ s.p16[3]) | 96u;
     uint32_t bits = b0 < b1 ? b0 : b1;
     const uint32_t bh = b2 < b3 ? b2 : b3;
     bits = bits < bh ? bits : bh;
@@ -1150,10 +1171,10 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     const uint32_t delta = lf_me(imp) ? len - 1 - s.bm1 : 0u;
     s.bestd = lf_me(imp) ? s.prel - cpos : s.bestd;
     s.bm1 += delta;
-    s.bb2 += 2 * delta;
-    s.lowa2 += 2 * delta;
+    s.bb2 += delta << W::SH;
+    s.lowa2 += delta << W::SH;
     const lane_flag full = imp & lf_of(len == s.maxlen);
-    const uint32_t pr = w.pair_at(tbase + 2 * (s.prel + s.bm1));
+    const uint32_t pr = w.key_at(tbase + ((s.prel + s.bm1) << W::SH));
     s.probe = lf_me(imp) ? pr : s.probe;
     s.offb = lf_me(hit) ? ho - 2 : s.offb;
     const lane_flag more = lf_of((int32_t)s.offb >= (int32_t)s.endb);
@@ -1169,8 +1190,9 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     }
     s.offb = lf_me(sw) ? s.offb2 : s.offb;
     s.endb = lf_me(sw) ? s.endb2 : s.endb;
-    s.bb2 = lf_me(sw) ? tbase + 2 * s.bm1 : s.bb2;
+    s.bb2 = lf_me(sw) ? tbase + (s.bm1 << W::SH) : s.bb2;
     s.in_prev = s.in_prev | sw;
+    s.has2 = lf_and_not(s.has2, sw);
     s.walk = lf_and_not(s.walk | resume | sw, s.done);
 }
 

@@ -162,14 +162,15 @@ void stage_match(Sim& s) {
                     swl_result(ln, &m, &mq);
                 };
                 // the k_match3 form: pair table, groups of four probes, the service decodes where a lane stopped
-                struct PWin {
+                struct PWin {  // pair table: the key is the pair, entries and addresses count two bytes per position
+                    enum : uint32_t { SH = 1 };
                     const uint8_t* d;  // position 0 of the window
                     uint64_t nb;       // readable bytes from d
                     const uint16_t* ps;
                     const uint16_t* cs;
                     uint32_t np, nc;
                     uint32_t byte(uint64_t k) const { return k < nb ? d[k] : 0u; }
-                    uint32_t pair_at(uint32_t a) const { return byte(a >> 1) | (byte((a >> 1) + 1) << 8); }  // (tbase = 0)
+                    uint32_t key_at(uint32_t a) const { return byte(a >> 1) | (byte((a >> 1) + 1) << 8); }  // (tbase = 0)
                     uint32_t load32(uint32_t k) const { return byte(k) | (byte(k + 1) << 8) | (byte(k + 2) << 16) | (byte(k + 3) << 24); }
                     void load16(uint32_t k, uint32_t* q) const {
                         for (int i = 0; i < 4; i++) q[i] = load32(k + 4 * i);
@@ -179,34 +180,55 @@ void stage_match(Sim& s) {
                         return i < np ? 2u * ps[i] : 0u;
                     }
                 };
-                auto run6 = [&](auto& ln) {
-                    PWin pw{s.in.data() + wbase, (uint64_t)s.in.size() - wbase, prevS.data(), curS.data(), (uint32_t)prevS.size(),
-                            (uint32_t)curS.size()};
+                struct HWin : PWin {  // k_match4: one byte per position, an 8-bit hash of the pair
+                    enum : uint32_t { SH = 0 };
+                    uint32_t key_at(uint32_t a) const { return pair_key8(byte(a), byte(a + 1)); }
+                    uint32_t sidx(uint32_t i) const {
+                        if (i >= SW_OWN) return i - SW_OWN < nc ? (uint32_t)cs[i - SW_OWN] : 0u;
+                        return i < np ? (uint32_t)ps[i] : 0u;
+                    }
+                };
+                auto run6 = [&](auto& ln, auto pw) {
+                    pw.d = s.in.data() + wbase;
+                    pw.nb = (uint64_t)s.in.size() - wbase;
+                    pw.ps = prevS.data();
+                    pw.cs = curS.data();
+                    pw.np = (uint32_t)prevS.size();
+                    pw.nc = (uint32_t)curS.size();
                     (void)swg_setup(ln, pw, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
                     ln.done = lf_not(ln.walk);
-                    lane_flag dropped = (j % 3) ? swg_first(ln, pw) : lf_of(false);  // (with and without the short cut)
+                    const uint32_t width = (j & 4) ? 8u : 4u;  // (groups of four and of eight steps)
+                    lane_flag dropped = (j % 3) ? swg_first(ln, pw, width) : lf_of(false);  // (with and without the short cut)
                     int d = dropped ? 0 : -1;
                     uint32_t guard = 0;
                     for (;;) {
-                        if (lf_me(dropped))
-                            swg_service(ln, pw, 0u, cq, dropped, lf_of(d == 0), lf_of(d == 1), lf_of(d == 2), lf_of(d == 3), ln.a0, ln.a1,
-                                        ln.a2, ln.a3);
+                        if (lf_me(dropped)) {
+                            const uint32_t av[8] = {ln.a0, ln.a1, ln.a2, ln.a3, ln.a4, ln.a5, ln.a6, ln.a7};
+                            swg_service(ln, pw, 0u, cq, dropped, lf_of(d >= 0), d >= 0 ? av[d] : 0u, ln.offb + 2 * (width - (d >= 0 ? d : 0)));
+                        }
                         if (!lf_me(ln.walk)) break;
                         const uint32_t groups = 1 + (guard % 3);
                         d = -1;
-                        for (uint32_t g = 0; g < groups && lf_me(ln.walk); g++) swg_group_ref(ln, pw, &d);
+                        for (uint32_t g = 0; g < groups && lf_me(ln.walk); g++) swg_group_ref(ln, pw, &d, width);
                         dropped = lf_not(ln.walk);
                         if (++guard > 100000) break;
                     }
                     swg_result(ln, &m, &mq);
                 };
                 if (g_multi == 6) {
+                    // (the pair table of k_match3 and the pair-hash table of k_match4, turn and turn about)
                     if (hasq) {
                         SwG<true> ln;
-                        run6(ln);
+                        if (j & 8)
+                            run6(ln, HWin());
+                        else
+                            run6(ln, PWin());
                     } else {
                         SwG<false> ln;
-                        run6(ln);
+                        if (j & 8)
+                            run6(ln, HWin());
+                        else
+                            run6(ln, PWin());
                     }
                 } else if (g_multi == 5) {
                     if (hasq) {

@@ -124,7 +124,7 @@ def test_block_part_boundaries(da, ctx):
 
 
 def test_large_host_input_goes_over_in_pieces(da, ctx):
-    """mi355_deflate_encode copies a host input of 16 MiB or more in eight pieces and starts sorting / walking
+    """mi355_deflate_encode copies a host input of 16 MiB or more in two pieces (a head of about 0.3 n, then the rest) and starts sorting / walking
     the first epochs while the rest is on the bus (deflate_host.inc encode_host, launch_match_tables): same
     bytes as the oracle, for the sizes around a piece boundary, raw and zlib, and for a level on the other paths."""
     base = datagen.text_like(21_000_000, 123)
@@ -490,13 +490,11 @@ def _drive(enc_new, ref_new, data, cuts, flush_at_end=False, chunk=0):
 
     def put(piece):
         # one write() call per `chunk` bytes (the reference's hash re-warm after a flush depends on the
-        # call pattern, lz77.rs:601-638); never a 1-byte call
+        # call pattern, lz77.rs:601-638)
         step = chunk or max(len(piece), 1)
         i = 0
         while i < len(piece):
             j = i + step
-            if len(piece) - j == 1:
-                j += 1
             enc.write_all(piece[i:j])
             ref.write_all(piece[i:j])
             i = j
@@ -537,10 +535,6 @@ def test_flush_with_window_retention(da, ctx, level):
                     ([5, 40000], 0), ([100, 200, 300, 50000], 0), ([32768, 40000], 0), ([32767, 33000, 70000], 0),
                     ([31744], 0), ([31744, 63488], 0), ([100], 1500), ([3, 9], 7000), ([31000], 33000), ([31000], 40000), (sorted(rnd.sample(range(3, 32768), 5)), 1500)]
         for cuts, chunk in cut_sets:
-            # every write after a flush must carry >= 2 bytes (the 1-byte quirk is refused, tested below)
-            ok = all(b - a != 1 for a, b in zip(cuts, cuts[1:] + [n])) and all(x == 0 or x >= 3 for x in cuts)
-            if not ok:
-                continue
             for wrapper, cls in ((0, da.DeflateEncoder), (1, da.ZlibEncoder)):
                 got = _drive(lambda: cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx),
                              lambda: ob.Stream(ob.make_opts(c, l, m, wrapper)), data, cuts,
@@ -715,6 +709,12 @@ def test_issue_26_and_the_write_patterns_around_a_flush(da, ctx):
         [txt[:150_000], "F", txt[150_000:200_000], "F", per[:1], per[1:50000], "F", per[50000:50001], "F", per[50001:120000]],
         [per[:30000], "F", per[30000:30001], "F", per[30001:30002], "F", per[30002:30003], per[30003:30004], "F", per[30004:100000]],
         [per[:30000], "F", per[30000:30001], per[30001:30002], "F", per[30002:30003], "F", per[30003:100000]],
+        # three [flush, write(1), write(10)] cycles past 96 KiB, then a write that makes the next flush trim the history:
+        # the trim keeps one flush point but every later skew point and hole (round 2 refused this at finish())
+        [txt[:100_000], "F", txt[100_000:100_001], txt[100_001:100_011], "F", txt[100_011:100_012], txt[100_012:100_022], "F",
+         txt[100_022:100_023], txt[100_023:100_033], "F", txt[100_033:132_033], "F", txt[132_033:200_000]],
+        [per[:100_000], "F"] + sum(([per[100_000 + 11 * k:100_001 + 11 * k], per[100_001 + 11 * k:100_011 + 11 * k], "F"]
+                                    for k in range(6)), []) + [per[100_066:140_000], "F", per[140_000:200_000]],
     ]
     refused = 0
     for lv in ("default", "fast", "best"):
