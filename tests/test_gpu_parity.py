@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI of include/mi355_deflate.h) against the
 CPU oracle -- bit-exact, every level, the reference's own fixtures, edge sizes, quirks -- plus
 size-independent properties at BASELINE sizes.  Needs a real MI355X: pytest -m gpu."""
+import ctypes as C
 import glob
 import os
 import sys
@@ -687,6 +688,104 @@ def test_long_stream_keeps_only_its_window(da, ctx, level):
             assert mid[0] == mid[1]
 
 
+# ---- SURVEY section 8 row g: inputs of any length, never-flushed streams in bounded memory (deflate_long.inc) ----
+def _set_long(da, range_bytes, from_bytes):
+    da.load().mi355_debug_set_long.argtypes = [C.c_uint64, C.c_uint64]
+    da.load().mi355_debug_set_long(range_bytes, from_bytes)
+
+
+@pytest.fixture
+def small_ranges(da):
+    """16 MiB ranges, every one-shot call of 20 MB or more goes through them"""
+    _set_long(da, 16 << 20, 20_000_000)
+    yield
+    _set_long(da, 512 << 20, (1 << 30) + 1)
+
+
+def test_long_input_walked_in_ranges(da, ctx, small_ranges):
+    """One call, several ranges (the phases of the sharded encode one after the other on one GPU, the bit position and
+    the unfinished block carried across): the bytes of a single-range call, i.e. of the oracle -- text, zeros (a range
+    is a few blocks), noise (stored blocks across the seams, Q1), a mix; every level; raw, zlib and gzip; host and
+    device buffers."""
+    import torch
+    cases = [("text", datagen.text_like(52_000_000, 77), ("default", "fast", "best")),
+             ("zeros", bytes(40_000_000), ("default", "rle")),
+             ("noise", datagen.rng_bytes(36_000_000, 78), ("default",)),
+             ("mixed", datagen.mixed(34_000_000, 79) + datagen.text_like(8_000_000, 80), ("default", "huffman_only"))]
+    for name, data, levels in cases:
+        for lv in levels:
+            c, l, m = LV[lv]
+            for wrapper in (0, 1, 2):
+                if wrapper and lv not in ("default",):
+                    continue
+                want = ob.encode(data, opts=ob.make_opts(c, l, m, wrapper)) if wrapper < 2 else ob.encode_gzip(
+                    data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, m, 0))
+                got = ctx.encode(data, da.CompressionOptions(c, l, m), wrapper=wrapper)
+                assert got == want, (name, lv, wrapper, len(got), len(want))
+                assert ctx.info()["passes"] >= 2, "the call was meant to take several ranges"
+            # device buffers
+            d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            cap = da.bound(len(data)) + 8
+            d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            n = ctx.encode_device(d_in.data_ptr(), len(data), d_out.data_ptr(), cap, da.CompressionOptions(c, l, m))
+            assert bytes(d_out[:n].cpu().numpy()) == ob.encode(data, opts=ob.make_opts(c, l, m, 0)), (name, lv, "device")
+
+
+def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
+    """write() hands a range over whenever one has filled up with its margin behind it (output independent of the write
+    chunking, lib.rs:408-433): the handle never holds more than a range, the margin, a window and a write; the bytes
+    are the oracle's; a flush() later ends the ranges with the sync marker and the stream goes on as a flushed one."""
+    import io
+    import random
+    data = datagen.text_like(70_000_000, 91)
+    L = da.load()
+    L.mi355_debug_stream_held.restype = C.c_uint64
+    L.mi355_debug_stream_held.argtypes = [C.c_void_p]
+    for wrapper, cls, lv in ((0, da.DeflateEncoder, "default"), (1, da.ZlibEncoder, "default"), (2, da.GzEncoder, "fast")):
+        c, l, m = LV[lv]
+        for flush_at in (None, 45_000_000):
+            rnd = random.Random(wrapper)
+            enc = cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+            ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+            if wrapper == 2:
+                ref.gzip_header(da.BLANK_GZIP_HEADER)
+            pos, held, mid = 0, 0, None
+            while pos < len(data):
+                step = rnd.choice([1, 5000, 65_536, 1_000_003, 3_500_000])
+                if flush_at and pos < flush_at <= pos + step:
+                    step = flush_at - pos
+                enc.write_all(data[pos:pos + step])
+                ref.write_all(data[pos:pos + step])
+                pos += step
+                held = max(held, L.mi355_debug_stream_held(enc._s))
+                if flush_at and pos == flush_at:
+                    enc.flush()
+                    ref.flush()
+                    assert enc._w.getvalue().endswith(b"\x00\x00\xff\xff")
+                if mid is None and pos > 40_000_000 and wrapper:
+                    mid = (enc.checksum(), ref.checksum())
+            got = enc.finish().getvalue()
+            assert got == ref.finish(), (wrapper, flush_at)
+            if mid:
+                assert mid[0] == mid[1]
+            # range 16 MiB + margin 16 MiB + look-ahead + window + the largest write, not the 70 MB of the stream
+            assert held < 42_000_000, held
+
+
+def test_input_beyond_2_31(da, ctx):
+    """2^31 + 2^20 bytes of the web-text input in one call: positions beyond 2^31, 512 MiB ranges, against the oracle's
+    digest (tests/golden/long_digest.json, gen_long_digest.py)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long_digest.json")))["digest"]
+    _set_long(da, 512 << 20, (1 << 30) + 1)
+    data = datagen.webtext(gold["in_len"])
+    assert hashlib.sha256(data).hexdigest() == gold["in_sha256"]
+    got = ctx.encode(data, da.Compression.Default)
+    assert len(got) == gold["out_len"] and hashlib.sha256(got).hexdigest() == gold["out_sha256"]
+    assert ctx.info()["passes"] >= 4
+
+
 # tests/test.rs:113-123 issue_26 (write, flush, one-byte write, write, drop) and its relatives: a one-byte
 # write right after a flush files one position less and two a byte late (lz77.rs:605-614), a flush after
 # one or two bytes leaves the first positions out of the chains and re-warms the hash (lz77.rs:606,628-638).
@@ -1009,6 +1108,10 @@ def test_c_example_program(tmp_path):
     subprocess.run(["gcc", "-O2", "-std=c99", "-I", os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "examples", "mi355_deflate_cli.c"), "-L", os.path.join(ROOT, "deflate-rs_amd"),
                     "-lmi355deflate", "-Wl,-rpath," + os.path.join(ROOT, "deflate-rs_amd"), "-o", exe], check=True)
+    trap = str(tmp_path / "segv_trap.so")
+    subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", trap, os.path.join(ROOT, "tools", "probes", "segv_trap.c"), "-ldl"],
+                   check=True)
+    env = dict(os.environ, LD_PRELOAD=trap)
     src = os.path.join(FIX, "pg11.txt")
     data = open(src, "rb").read()
     blank = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff])
@@ -1017,10 +1120,11 @@ def test_c_example_program(tmp_path):
         for extra in ([], ["-chunk", "5000"]):
             out = str(tmp_path / "out.bin")
             cmd = [exe, flag, lvl[0]] + extra + [src, out]
-            r = subprocess.run(cmd, capture_output=True)
-            if r.returncode < 0:  # killed by a signal: seen once in ~170 runs, at process exit, after the output
-                r = subprocess.run(cmd, capture_output=True)  # was written (clean under ASan); a second one fails
-            assert r.returncode == 0, (cmd, r.returncode, r.stderr[-500:])
+            # (no retry: round 2 saw one SIGSEGV at process exit in ~170 runs and hid it behind one; 2 100 runs under
+            # the fault trap in round 3 -- alone, four at a time, under a parent that holds a context -- had none,
+            # DESIGN.md.  The trap stays loaded so that a crash, should it come back, arrives with its backtrace.)
+            r = subprocess.run(cmd, capture_output=True, env=env)
+            assert r.returncode == 0, (cmd, r.returncode, r.stderr[-3000:])
             got = open(out, "rb").read()
             if flag == "-gzip":
                 want = ob.encode_gzip(data, blank, level=lvl[1])
