@@ -772,6 +772,47 @@ def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
             assert held < 42_000_000, held
 
 
+def test_stream_beyond_4gib_without_flush(da, ctx):
+    """A ZlibEncoder fed 4.25 GiB (64 MiB of web text, 68 times over) and never flushed: positions beyond 2^32, 512 MiB
+    ranges handed over as they fill, the handle holds a range and its margin, not the stream; the stream inflates to
+    the input (checked piece by piece) and ends in its Adler-32."""
+    import io
+    block = datagen.webtext(64 << 20)
+    reps = 68
+    _set_long(da, 512 << 20, (1 << 30) + 1)
+    L = da.load()
+    L.mi355_debug_stream_held.restype = C.c_uint64
+    L.mi355_debug_stream_held.argtypes = [C.c_void_p]
+
+    class Check:  # the inner writer: inflates what it is given and compares it with the input, keeps nothing
+        def __init__(self):
+            self.d = zlib.decompressobj()
+            self.pos = 0
+            self.n = 0
+
+        def write(self, b):
+            self.n += len(b)
+            out = self.d.decompress(b)
+            o = 0
+            while o < len(out):
+                k = min(len(out) - o, len(block) - self.pos % len(block))
+                assert out[o:o + k] == block[self.pos % len(block):self.pos % len(block) + k], self.pos
+                o += k
+                self.pos += k
+
+    sink = Check()
+    enc = da.ZlibEncoder(sink, da.Compression.Default, ctx)
+    held = 0
+    for _ in range(reps):
+        for o in range(0, len(block), 32 << 20):
+            enc.write_all(block[o:o + (32 << 20)])
+            held = max(held, L.mi355_debug_stream_held(enc._s))
+    enc.finish()
+    assert sink.d.eof and sink.pos == reps * len(block)  # (zlib has checked the Adler-32 of all 4.25 GiB)
+    assert held < (512 << 20) + (96 << 20), held
+    assert sink.n < 0.5 * sink.pos
+
+
 def test_input_beyond_2_31(da, ctx):
     """2^31 + 2^20 bytes of the web-text input in one call: positions beyond 2^31, 512 MiB ranges, against the oracle's
     digest (tests/golden/long_digest.json, gen_long_digest.py)."""
