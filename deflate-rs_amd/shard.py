@@ -310,42 +310,55 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
         ranges.append((base // 8, (e - base + 7) // 8))
     b0 = starts[rank]
     end_bit = plans[b0 + nb].bit_start if b0 + nb < ntot else total_bits
-    # round 4: byte ranges to rank 0, all in flight at once (every peer has its own xGMI link to rank 0) and
-    # posted before rank 0 packs its own blocks; then OR-ed in: neighbours share the seam byte
+    # round 4: byte ranges to rank 0, all in flight at once (every peer has its own xGMI link to rank 0), posted before
+    # rank 0 packs its own blocks and received STRAIGHT INTO the stream image at their byte offsets.  Neighbours share
+    # at most the 32-bit word a range starts in (mi355_shard_pack begins at a word boundary): that word -- the "head"
+    # of a range -- travels on its own and is OR-ed in, everything behind it is plain data.  The image is kept
+    # between steps and never cleared: only the head words are zeroed before the data of the range before them lands.
     hl = 0
-    out = None
-    tmps, reqs = {}, []
+    tl = {1: 4, 2: 8}.get(wrapper, 0)
+    if wrapper == 1:
+        hl = 2
+    elif wrapper == 2:
+        gzip_header = bytes(gzip_header) if gzip_header is not None else da.BLANK_GZIP_HEADER
+        hl = len(gzip_header)
+    reqs = []
+    img = heads = None
     if rank == 0:
-        if wrapper == 1:
-            hl = 2
-        elif wrapper == 2:
-            gzip_header = bytes(gzip_header) if gzip_header is not None else da.BLANK_GZIP_HEADER
-            hl = len(gzip_header)
+        img = _cached("img", cdev, hl + stream_len + 24 + tl)
+        heads = _cached("heads", cdev, 4 * world)
         ops = []
         for r in range(1, world):
             f, k = ranges[r]
-            if k:
-                tmps[r] = torch.empty(k, dtype=torch.uint8, device=cdev)
-                ops.append(dist.P2POp(dist.irecv, tmps[r], r, group))
+            if not k:
+                continue
+            img[hl + f:hl + f + min(4, k)].zero_()
+            ops.append(dist.P2POp(dist.irecv, heads[4 * r:4 * r + min(4, k)], r, group))
+            if k > 4:
+                ops.append(dist.P2POp(dist.irecv, img[hl + f + 4:hl + f + k], r, group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        out = torch.zeros(hl + stream_len + 24, dtype=torch.uint8, device=dev)
+        mark("x4 post receives")
     fb, nbytes = 0, 0
     dev_out = None
     if nb:
         cap = (end_bit - plans[b0].bit_start) // 8 + 64
-        dev_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        dev_out = _cached("pack", dev, cap)
         fb, nbytes = sh.pack_raw(plans, b0, end_bit, dev_out.data_ptr(), cap)
         assert (fb, nbytes) == ranges[rank]
     mark("pack")
     sh.close()
     if rank == 0:
-        if nbytes:
-            out[hl + fb:hl + fb + nbytes] |= dev_out[:nbytes]
+        if nbytes:  # (rank 0's range starts the stream: nothing of a neighbour lies under it)
+            img[hl + fb:hl + fb + nbytes] = dev_out[:nbytes] if cdev.type == dev.type else dev_out[:nbytes].to(cdev)
+        mark("x4 own bytes")
         for q in reqs:
             q.wait()
-        for r, t in tmps.items():
+        mark("x4 wait for the peers' bytes")
+        for r in range(1, world):
             f, k = ranges[r]
-            out[hl + f:hl + f + k] |= t.to(dev)
+            if k:
+                h = min(4, k)
+                img[hl + f:hl + f + h] |= heads[4 * r:4 * r + h]
         n_out = hl + stream_len
         if wrapper:
             L_ = da.load()
@@ -353,26 +366,50 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
             for r in range(world):
                 acc = L_.mi355_checksum_combine(wrapper, acc, sums[r], lays[r]["b"] - lays[r]["a"])
             if wrapper == 1:  # zlib.rs:59-62, lib.rs:192-196
-                frame = torch.tensor([0x78, 0x9C], dtype=torch.uint8, device=dev)
-                trailer = torch.tensor(list(acc.to_bytes(4, "big")), dtype=torch.uint8, device=dev)
+                frame = torch.tensor([0x78, 0x9C], dtype=torch.uint8, device=cdev)
+                trailer = torch.tensor(list(acc.to_bytes(4, "big")), dtype=torch.uint8, device=cdev)
             else:             # lib.rs:250-266
-                frame = torch.tensor(list(gzip_header), dtype=torch.uint8, device=dev)
+                frame = torch.tensor(list(gzip_header), dtype=torch.uint8, device=cdev)
                 trailer = torch.tensor(list(acc.to_bytes(4, "little")) + list((total & 0xFFFFFFFF).to_bytes(4, "little")),
-                                       dtype=torch.uint8, device=dev)
-            out[:hl] = frame
-            out[n_out:n_out + trailer.numel()] = trailer
+                                       dtype=torch.uint8, device=cdev)
+            img[:hl] = frame
+            img[n_out:n_out + trailer.numel()] = trailer
             n_out += trailer.numel()
-        mark("x4 stitch")
+        mark("x4 seams + framing")
+        out = img[:n_out] if cdev.type == dev.type else img[:n_out].to(dev)  # (gloo dry run: the image was gathered in host memory)
+        mark("x4 image to the device (gloo only)")
         if trace:
             LAST_TRACE.clear()
             LAST_TRACE.update({marks[i][0]: round(1e3 * (marks[i][1] - marks[i - 1][1]), 3) for i in range(1, len(marks))})
-        return out[:n_out], n_out
+        return out, n_out
     if nbytes:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, dev_out[:nbytes].to(cdev).contiguous(), 0, group)]):
+        src = dev_out[:nbytes] if cdev.type == dev.type else dev_out[:nbytes].to(cdev)
+        ops = [dist.P2POp(dist.isend, src[:min(4, nbytes)], 0, group)]
+        if nbytes > 4:
+            ops.append(dist.P2POp(dist.isend, src[4:], 0, group))
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-    tl = {1: 4, 2: 8}.get(wrapper, 0)
-    hl = {1: 2, 2: len(bytes(gzip_header) if gzip_header is not None else da.BLANK_GZIP_HEADER)}.get(wrapper, 0)
     return None, stream_len + hl + tl
+
+
+_CACHE = {}
+
+
+def _cached(name, device, nbytes):
+    """a uint8 buffer of at least nbytes on `device`, kept between steps (pinned when it is host memory)"""
+    import torch
+    key = (name, str(device))
+    t = _CACHE.get(key)
+    if t is None or t.numel() < nbytes:
+        n = nbytes + nbytes // 8 + 64
+        t = torch.empty(n, dtype=torch.uint8, device=device)
+        if t.device.type == "cpu" and torch.cuda.is_available():
+            try:
+                t = t.pin_memory()
+            except RuntimeError:
+                pass
+        _CACHE[key] = t
+    return t
 
 
 def ctypes_copy_d2d(dst_ptr, src_ptr, nbytes):

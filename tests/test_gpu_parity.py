@@ -1042,6 +1042,49 @@ def test_randomized_streams(da, ctx):
     assert tally.get("ok", 0) >= 140
 
 
+# tests/test.rs:78-91 issue_44 (26 214 400 bytes, 99.99 % zeros with sparse disturbances: one giant hash bucket per
+# epoch -- the worst case of the sorted walk and of k_sort's hot digit), inflated, against the oracle
+def test_issue_44_on_the_gpu(da, ctx):
+    data = zlib.decompress(open(os.path.join(FIX, "issue_44.zlib"), "rb").read())
+    assert len(data) == 26214400
+    for lv in ("default", "best", "fast"):
+        c, l, m = LV[lv]
+        want = ob.encode(data, opts=ob.make_opts(c, l, m, 1))
+        got = ctx.encode(data, da.CompressionOptions(c, l, m), wrapper=1)
+        assert got == want, lv
+        assert zlib.decompress(got) == data
+
+
+# a slice of tools/fuzz_shard.py: random data kind, size, level and 2-8 virtual ranks (also ranges shorter than a
+# block) through the stream-exact sharded encode, against the oracle
+def test_randomized_shards(da):
+    import random
+    import shard
+    ctxs = [da.Context(0) for _ in range(8)]
+    tally = {}
+    for seed in range(1, 41):
+        rnd = random.Random(seed * 7919)
+        world = rnd.choice([2, 3, 4, 5, 8])
+        kind = rnd.choice(["text", "mixed", "rng", "zeros", "period"])
+        n = rnd.randrange(world * 140000, world * 140000 + 3_000_000)  # every rank needs more than its halo
+        s2 = rnd.randrange(1 << 30)
+        data = {"text": lambda: datagen.text_like(n, s2), "mixed": lambda: datagen.mixed(n, s2), "rng": lambda: datagen.rng_bytes(n, s2),
+                "zeros": lambda: bytes(n),
+                "period": lambda: (datagen.rng_bytes(rnd.choice([3, 300, 4099, 32769]), s2) * (n // 3 + 1))[:n]}[kind]()
+        c, l, m = rnd.choice([(1, 0, 0), (128, 32, 1), (128, 32, 1), (0, 0, 1), (0, 0, 0), (32, 8, 1), (500, 64, 1)])
+        try:
+            ref = ob.encode(data, opts=ob.make_opts(c, l, m))
+        except ob.RefPanic:
+            tally["ref-panic"] = tally.get("ref-panic", 0) + 1
+            continue
+        got = shard.encode_p1_virtual(da, ctxs[:world], data, da.CompressionOptions(c, l, m), compat=1)
+        assert got == ref, (seed, world, kind, n, (c, l, m))
+        tally["ok"] = tally.get("ok", 0) + 1
+    assert tally.get("ok", 0) >= 36, tally
+    for cx in ctxs:
+        cx.close()
+
+
 # the committed digests of the oracle's streams (tests/golden/oracle_digests.json): every reference fixture,
 # every level, raw / zlib / gzip
 def test_golden_digests(da, ctx):
