@@ -1192,6 +1192,12 @@ template <bool HAS_Q>
 __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_t* sb8, uint64_t walkx, uint64_t walky,
                                               uint64_t* stillx, uint64_t* stilly) {
     uint64_t save, cx, cy;
+    {   // (the base must sit in scalar registers; under register pressure the compiler has kept it in vector ones)
+        const uint64_t v = (uint64_t)(uintptr_t)sb8;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        sb8 = (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "s_mov_b64 exec, %[wx]\n\t"
@@ -1240,7 +1246,8 @@ template <bool HAS_Q>
 __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                                 uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
-                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split) {
+                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
+                                                uint32_t* __restrict__ Mqs) {
     __shared__ __attribute__((aligned(16))) uint4 s_T[M3_PAIRS / 8];  // T[k] = byte k | byte k+1 << 8, k from the window's start
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1337,6 +1344,8 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
 #if MI355_M3_DUAL
+    uint32_t* const Mo = Ms ? Ms : M;      // where a batch's results go: in the order of S_e (turned round at the end), else by position
+    uint32_t* const Mqo = Ms ? Mqs : Mq;
     uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
     for (;;) {
         uint32_t b = 0;
@@ -1352,12 +1361,12 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifndef MI355_M3_NOSTORE
         // (the results of the pair before go out here, behind this pair's set-up loads: see k_match2)
         if (pxat != ~0u) {
-            M[E + pxat] = pxm;
-            if (HAS_Q) Mq[E + pxat] = pxq;
+            Mo[E + pxat] = pxm;
+            if (HAS_Q) Mqo[E + pxat] = pxq;
         }
         if (pyat != ~0u) {
-            M[E + pyat] = pym;
-            if (HAS_Q) Mq[E + pyat] = pyq;
+            Mo[E + pyat] = pym;
+            if (HAS_Q) Mqo[E + pyat] = pyq;
         }
 #endif
         // the first candidate of every lane goes straight to the service
@@ -1380,18 +1389,41 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         swg_result(sx, &pxm, &pxq);
         swg_result(sy, &pym, &pyq);
-        pxat = vx ? srx : ~0u;
-        pyat = vy ? sry : ~0u;
+        pxat = vx ? (Ms ? b * 64 + lane : srx) : ~0u;
+        pyat = vy ? (Ms ? b * 64 + 64 + lane : sry) : ~0u;
         M2_T(13)
     }
 #ifndef MI355_M3_NOSTORE
     if (pxat != ~0u) {
-        M[E + pxat] = pxm;
-        if (HAS_Q) Mq[E + pxat] = pxq;
+        Mo[E + pxat] = pxm;
+        if (HAS_Q) Mqo[E + pxat] = pxq;
     }
     if (pyat != ~0u) {
-        M[E + pyat] = pym;
-        if (HAS_Q) Mq[E + pyat] = pyq;
+        Mo[E + pyat] = pym;
+        if (HAS_Q) Mqo[E + pyat] = pyq;
+    }
+    if (Ms) {
+        // The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position
+        // they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for
+        // 0.4 GB of M).  Now that the walk is over the pair table is not needed any more: its LDS takes the epoch's
+        // results by position, and they leave as whole lines.
+        uint32_t* const lm = reinterpret_cast<uint32_t*>(s_T);
+        const uint32_t cnt = (uint32_t)((uint64_t)n - E < (uint64_t)WINDOW_SIZE ? (uint64_t)n - E : (uint64_t)WINDOW_SIZE);
+        for (int pass = 0; pass < (HAS_Q ? 2 : 1); pass++) {
+            const uint32_t* src = pass ? Mqs : Ms;
+            uint32_t* dst = pass ? Mq : M;
+            __syncthreads();
+            for (uint32_t j = tid; j < J; j += M3T) lm[(uint32_t)own[j] >> 1] = src[E + j];
+            if (tid < 2 && J + tid < cnt) lm[J + tid] = 0;  // the positions without a hash byte
+            __syncthreads();
+            for (uint32_t i = tid * 4; i < cnt; i += M3T * 4) {
+                if (i + 4 <= cnt) {
+                    *reinterpret_cast<uint4*>(dst + E + i) = *reinterpret_cast<const uint4*>(lm + i);
+                } else {
+                    for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k];
+                }
+            }
+        }
     }
 #endif
 #else

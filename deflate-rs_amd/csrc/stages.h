@@ -1148,15 +1148,23 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     uint32_t len = (bits < 128u ? bits : 128u) >> 3;
     const lane_flag lng = hit & lf_of(len == 16 && s.maxlen > 16);
     if (lf_any(lng)) {
-        if (lf_me(lng)) {
+        if (lf_me(lng)) {  // sixteen more bytes per round (runs of one byte take sixteen rounds to 258)
             while (len < s.maxlen) {
-                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(cpos + len + 4)) << 32) |
-                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(cpos + len));
-                if (x) {
-                    len += (uint32_t)__builtin_ctzll(x) >> 3;
+                uint32_t pa[4], ca[4];
+                w.load16(s.prel + len, pa);
+                w.load16(cpos + len, ca);
+                const uint32_t c0 = first_bit_or_ones(pa[0] ^ ca[0]);
+                const uint32_t c1 = first_bit_or_ones(pa[1] ^ ca[1]) | 32u;
+                const uint32_t c2 = first_bit_or_ones(pa[2] ^ ca[2]) | 64u;
+                const uint32_t c3 = first_bit_or_ones(pa[3] ^ ca[3]) | 96u;
+                uint32_t cb = c0 < c1 ? c0 : c1;
+                const uint32_t ch = c2 < c3 ? c2 : c3;
+                cb = cb < ch ? cb : ch;
+                if (cb < 128u) {
+                    len += cb >> 3;
                     break;
                 }
-                len += 8;
+                len += 16;
             }
         }
     }
