@@ -605,8 +605,29 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     (void)ks_t;
     for (uint32_t k = tid; k < WINDOW_SIZE / 2; k += 1024) sBuf[k] = 0;
     __syncthreads();
-    // hashes (chained_hash_table.rs:55-62) and their histogram; eight positions per thread and round so
-    // that the loads of a round are in flight together
+    // hashes (chained_hash_table.rs:55-62) and their histogram.  A full epoch of a 16-byte aligned input: a thread takes
+    // eight consecutive positions from two aligned dwords and the one behind them (one byte-granular dword load per
+    // position kept the address unit busy for a quarter of the kernel); else eight positions per thread and round,
+    // one clamped load each.
+    const bool whole = J == WINDOW_SIZE && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && E + WINDOW_SIZE + 4 <= (uint64_t)n &&
+                       !(ov.on | ov.m);
+    if (whole) {
+#pragma unroll
+        for (uint32_t r = 0; r < WINDOW_SIZE / (8 * 1024); r++) {
+            const uint32_t i = (r * 1024 + tid) * 8;
+            const uint2 w = *reinterpret_cast<const uint2*>(in + E + i);
+            const uint32_t nx = *reinterpret_cast<const uint32_t*>(in + E + i + 8);
+            const uint32_t d[3] = {w.x, w.y, nx};
+            uint32_t hs[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t v = (k & 3) ? __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t)(k & 3)) : d[k >> 2];
+                hs[k] = hash3(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff);
+                atomicAdd(&sBuf[hs[k] >> 1], (hs[k] & 1) ? 0x10000u : 1u);
+            }
+            *reinterpret_cast<uint4*>(&sH[i]) = make_uint4(hs[0] | (hs[1] << 16), hs[2] | (hs[3] << 16), hs[4] | (hs[5] << 16), hs[6] | (hs[7] << 16));
+        }
+    } else
     for (uint32_t i0 = 0; i0 < J; i0 += 8 * 1024) {
         uint32_t v[8];
 #pragma unroll

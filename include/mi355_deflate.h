@@ -29,8 +29,9 @@ extern "C" {
 #define MI355_E_ARG (-1)           /* null pointer / bad option */
 #define MI355_E_OUT_TOO_SMALL (-2) /* *out_len holds the size needed */
 #define MI355_E_HIP (-3)           /* HIP runtime error; see mi355_deflate_last_error */
-#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching, or
-                                      input >= 4 GiB - 64 KiB in one call */
+#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching; a sync-flush chunk
+                                      (MI355_FLUSH_SYNC) of 4 GiB - 64 KiB or more in one call; 4 GiB - 64 KiB or more
+                                      written since the last flush() of a stream that has been flushed before */
 #define MI355_E_REF_PANIC (-5)     /* the reference itself panics on this input (A.4 Q13, slice out
                                       of range) and MI355_COMPAT_Q13 was requested */
 #define MI355_E_STATE (-6)         /* stream used after finish */
@@ -102,7 +103,11 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
  * in, host buffer out.  ctx may be NULL (the default context, see above).  An input of 16 MiB or more is
  * copied in two pieces and worked on while the second is still on the bus; that only overlaps when `in` is
- * page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap. */
+ * page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap.
+ * Any in_len is taken, like src/lib.rs:137-147: an input of more than 1 GiB is walked as consecutive ranges of
+ * 512 MiB (csrc/deflate_long.inc -- the phases of the sharded encode below, one range after the other on this
+ * GPU; the same bytes as a single pass), which also bounds the device memory of a call: two workspaces of
+ * about 20 B per byte of a range. */
 int mi355_deflate_encode(mi355_deflate_ctx* ctx, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
                          uint8_t* out, size_t out_cap, size_t* out_len);
 
@@ -119,7 +124,8 @@ int mi355_deflate_ctx_reserve(mi355_deflate_ctx* ctx, size_t in_len, int host_ap
  * smaller buffer is refused with MI355_E_OUT_TOO_SMALL and the size in *out_len).  `hip_stream` is a
  * hipStream_t (NULL = the context's own stream); the
  * call returns after the stream has drained, with *out_len set.  Always raw deflate unless
- * opts->wrapper == 1, in which case the 2-byte header and 4-byte trailer are written too. */
+ * opts->wrapper == 1, in which case the 2-byte header and 4-byte trailer are written too.
+ * Any in_len (more than 1 GiB: in ranges, see mi355_deflate_encode; the work then runs on the context's streams). */
 int mi355_deflate_encode_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len, const mi355_deflate_opts* opts,
                                 void* d_out, size_t out_cap, size_t* out_len, void* hip_stream);
 
@@ -234,12 +240,19 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  *   _take_output = hand over up to `cap` of them: the shim's loop over W::write, which may accept fewer
  *                  bytes than offered (src/compress.rs:96-124, 280-299; tests/test.rs:163-200 issue_47)
  *   _checksum    = {Zlib,Gz}Encoder::checksum()         :248-250 / :428-430
- * write() only gathers (the reference likewise does nothing until its 64 KiB + 258 buffer is full,
+ * write() gathers (the reference likewise does nothing until its 64 KiB + 258 buffer is full,
  * src/lz77.rs:627, and its output does not depend on how the input is split: src/lib.rs:408-433); the GPU
  * encodes at flush() and finish(), and the bytes of a flush -- ending in 00 00 FF FF, as
  * src/writer.rs:570-595 asserts -- are available when flush() returns.  Between flushes the handle keeps
  * the bytes since the last flush plus the 32 KiB window before it (the whole stream while the flushed part
- * is shorter than three windows).  One _write call stands for one write_all call (n == 0: no call at all);
+ * is shorter than three windows).  A stream that has NOT been flushed yet is bounded all the same (the
+ * reference's O(window) streaming, src/compress.rs:96-124): whenever 512 MiB and a margin of 16 MiB have
+ * gathered, write() encodes that range and makes its bytes available (_output / _take_output), keeping the
+ * rest, one window of history and the bytes not yet taken -- a stream of any length, e.g. 8 GiB into a
+ * ZlibEncoder without a single flush(), holds about 0.55 GiB of host memory.  A flush() of such a stream ends
+ * the ranges with the sync marker and the stream goes on as a flushed one; after a flush, what is written
+ * until the next flush() / finish() is encoded in one call and must stay below 4 GiB - 64 KiB
+ * (MI355_E_UNSUPPORTED from _write otherwise).  One _write call stands for one write_all call (n == 0: no call at all);
  * the size of the first write after a flush is remembered, because the reference's hash re-warm at a
  * flush point inside the first window depends on it (src/lz77.rs:601-638).  The shim's Drop calls _finish
  * and drains the output like the reference's (src/writer.rs:139-152). */
