@@ -1391,11 +1391,16 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
 #endif
         // the first candidate of every lane goes straight to the service
-        uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
-        for (;;) {
-            if (dx) settle(sx, dx);
-            if (dy) settle(sy, dy);
+        // (no finding out where they stopped: every lane concerned "left at the first probe of its group")
+        {
+            const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
+            if (dx) swg_service(sx, win, tbase, checks_q, dx, dx, sx.a0, sx.offb + 16u);
+            if (dy) swg_service(sy, win, tbase, checks_q, dy, dy, sy.a0, sy.offb + 16u);
+            M2_CNT(2, 2)
+            M2_CNT(3, __popcll(dx) + __popcll(dy))
             M2_T(9)
+        }
+        for (;;) {
             const uint64_t wx = sx.walk, wy = sy.walk;
             if ((wx | wy) == 0) break;
             M2_CNT(1, 1)
@@ -1405,8 +1410,10 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             M2_T(12)
             sx.walk = cx;
             sy.walk = cy;
-            dx = wx & ~cx;
-            dy = wy & ~cy;
+            const uint64_t dx = wx & ~cx, dy = wy & ~cy;
+            if (dx) settle(sx, dx);
+            if (dy) settle(sy, dy);
+            M2_T(9)
         }
         swg_result(sx, &pxm, &pxq);
         swg_result(sy, &pym, &pyq);

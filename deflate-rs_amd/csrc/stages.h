@@ -1069,13 +1069,13 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.offb = own ? 2 * (SW_OWN + j - 1) + 8 : s.offb2;
     s.endb = own ? s.offb + 2 - 2 * n1 : s.endb2;
     s.in_prev = lf_of(!own);
-    s.has2 = lf_of(own && n2 > 0);
+    s.has2 = lf_of(own) & lf_of(n2 > 0);
     s.seg0 = s.offb;
     s.bb2 = tbase + ((own ? bias : 0u) << W::SH);
     s.lowa2 = tbase + (s.low << W::SH);
     w.load16(prel, s.p16);
     s.probe = w.key_at(tbase + (prel << W::SH));
-    s.walk = lf_of(search && n1 + n2 > 0);
+    s.walk = lf_of(prel + 2 < nrel) & lf_of(checks > 0) & lf_of(n1 + n2 > 0);
     return search;
 }
 
@@ -1132,7 +1132,8 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
                           uint32_t asel, uint32_t ho) {
     // a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of the window
     // (positions fall along a segment, so the hit's own address tells), is no hit
-    const lane_flag hit = dany & lf_of((int32_t)ho >= (int32_t)s.endb && asel >= s.lowa2);  // matching.rs:102-106,127,141-143
+    // (one comparison per ballot: a ballot of `a && b` makes the compiler turn a lane mask into 0 / 1 values and back)
+    const lane_flag hit = dany & lf_of((int32_t)ho >= (int32_t)s.endb) & lf_of(asel >= s.lowa2);  // matching.rs:102-106,127,141-143
     lane_flag rend = lf_and_not(dropped, hit);  // the segment is used up, or its next candidate is out of reach
     // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
     const uint32_t cpos = ((asel - tbase) >> W::SH) - s.bm1;
@@ -1146,7 +1147,7 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     const uint32_t bh = b2 < b3 ? b2 : b3;
     bits = bits < bh ? bits : bh;
     uint32_t len = (bits < 128u ? bits : 128u) >> 3;
-    const lane_flag lng = hit & lf_of(len == 16 && s.maxlen > 16);
+    const lane_flag lng = hit & lf_of(len == 16) & lf_of(s.maxlen > 16);
     if (lf_any(lng)) {
         if (lf_me(lng)) {  // sixteen more bytes per round (runs of one byte take sixteen rounds to 258)
             while (len < s.maxlen) {
@@ -1189,18 +1190,21 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     const lane_flag hgo = lf_and_not(hit, full);
     rend = rend | lf_and_not(hgo, more);
     const lane_flag resume = hgo & more;
-    // end of the own epoch's segment: on to the previous epoch's bucket, if the budget reaches it
-    const lane_flag sw = lf_and_not(rend, s.in_prev) & lf_of((int32_t)s.offb2 >= (int32_t)s.endb2);
-    s.done = s.done | full | lf_and_not(rend, sw);
-    if (HAS_Q) {
-        s.vbase += lf_me(sw) ? ((s.seg0 - s.endb) >> 1) + 1 : 0u;
-        s.seg0 = lf_me(sw) ? s.offb2 : s.seg0;
+    lane_flag sw = lf_of(false);
+    if (lf_any(rend)) {
+        // end of the own epoch's segment: on to the previous epoch's bucket, if the budget reaches it
+        sw = rend & s.has2;
+        if (HAS_Q) {
+            s.vbase += lf_me(sw) ? ((s.seg0 - s.endb) >> 1) + 1 : 0u;
+            s.seg0 = lf_me(sw) ? s.offb2 : s.seg0;
+        }
+        s.offb = lf_me(sw) ? s.offb2 : s.offb;
+        s.endb = lf_me(sw) ? s.endb2 : s.endb;
+        s.bb2 = lf_me(sw) ? tbase + (s.bm1 << W::SH) : s.bb2;
+        s.in_prev = s.in_prev | sw;
+        s.has2 = lf_and_not(s.has2, sw);
     }
-    s.offb = lf_me(sw) ? s.offb2 : s.offb;
-    s.endb = lf_me(sw) ? s.endb2 : s.endb;
-    s.bb2 = lf_me(sw) ? tbase + (s.bm1 << W::SH) : s.bb2;
-    s.in_prev = s.in_prev | sw;
-    s.has2 = lf_and_not(s.has2, sw);
+    s.done = s.done | full | lf_and_not(rend, sw);
     s.walk = lf_and_not(s.walk | resume | sw, s.done);
 }
 
