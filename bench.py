@@ -260,7 +260,7 @@ def main():
         except AttributeError:
             mpath = int(os.environ.get("MI355_MATCH_PATH", "2"))
         sorted_walk = lvl in ("default", "best") and mpath != 1
-        dominant = "k_rle" if lvl == "rle" else ({4: "k_match3", 5: "k_match4"}.get(mpath, "k_match2") if sorted_walk else "k_match")
+        dominant = "k_rle" if lvl == "rle" else ({4: "k_match3", 5: "k_match4", 6: "k_match5"}.get(mpath, "k_match2") if sorted_walk else "k_match")
         # 1 B read + r B written per input byte; one launch of the dominant kernel = one rank's bytes
         algo_bytes = size + (total_out // world)
         achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0

@@ -1089,10 +1089,18 @@ struct PairWin {
     MS_G4(RD, "v58", "v59", "")                                          \
     "s_waitcnt vmcnt(0)\n\t"                                             \
     MS_G4(RD, "v56", "v57", "")
+// (a wave-uniform pointer the compiler has kept in vector registers, back in scalar ones: an asm operand needs them there)
+__device__ __forceinline__ const uint16_t* uniform_ptr(const uint16_t* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
 #define MS_STEPS(NAME, BODY, OPS8, ...)                                                                                       \
     template <bool HAS_Q>                                                                                                     \
     __device__ __forceinline__ uint64_t NAME(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {                             \
         uint64_t save, still;                                                                                                 \
+        sb8 = uniform_ptr(sb8);                                                                                               \
         asm volatile("s_mov_b64 %[save], exec\n\t"                                                                            \
                      "s_mov_b64 exec, %[walk]\n\t" BODY ".Lms_end%=:\n\t"                                                     \
                      "s_waitcnt vmcnt(0)\n\t"                                                                                 \
@@ -1501,6 +1509,8 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
 #endif
 }
+
+#include "match_queue.inc"
 
 // ---------------------------------------------------------------------------------------------
 // k_match4: the walk of k_match3 (stages.h SwG) over a table that fits the CU twice.  The probe never needs the

@@ -241,7 +241,7 @@ pub mod write {
                     if rc != 0 {
                         return Err(err("write", rc));
                     }
-                    drain(self.s, self.inner.as_mut().expect("writer"))?; // (the header, at the first write)
+                    drain(self.s, self.inner.as_mut().expect("writer"))?; // (the header at the first write; the ranges of a stream that has not been flushed, as they are encoded)
                     Ok(buf.len())
                 }
                 /// Flush::Sync (src/writer.rs:134-137): the inner writer holds everything up to and including
