@@ -1920,9 +1920,9 @@ struct TileM {
     }
 };
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
-                                             ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg) {
+                                             ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg, uint32_t blk0) {
     __shared__ __attribute__((aligned(16))) uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
-    const uint64_t t0 = (uint64_t)blockIdx.x * ADV_TILE;
+    const uint64_t t0 = ((uint64_t)blockIdx.x + blk0) * ADV_TILE;  // (blk0: a launch may cover a range of tiles)
     const bool useq = Mq != nullptr;
     // (the tables are padded by 64 entries and 256-byte aligned, a tile starts at a multiple of 1024 entries:
     // sixteen bytes per lane)
@@ -1970,10 +1970,10 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
 // is resolved at once (from the table of the chunks already done, kept in LDS); jumps that stay
 // inside the chunk are resolved by pointer jumping across lanes (<= 7 rounds).
 __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
-                                                  uint16_t* __restrict__ X0) {
+                                                  uint16_t* __restrict__ X0, uint32_t seg0) {
     __shared__ uint16_t sJ[4][SEG];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
     uint16_t* J = sJ[wv];
     const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
