@@ -1978,35 +1978,37 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
     uint16_t* J = sJ[wv];
     const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
     const uint32_t len = (uint32_t)(b - a);
-    for (int32_t c = (int32_t)((len - 1) / 64 * 64); c >= 0; c -= 64) {
+    // (all of the segment's jumps are fetched before the sweep: one load per chunk inside it was sixteen memory latencies
+    // in a row per wave, and those were the kernel's time)
+    uint16_t av[SEG / 64];
+#pragma unroll
+    for (uint32_t q = 0; q < SEG / 64; q++) av[q] = q * 64 + lane < len ? adv[a + q * 64 + lane] : (uint16_t)0;
+#pragma unroll
+    for (int32_t q = (int32_t)(SEG / 64) - 1; q >= 0; q--) {
+        const int32_t c = q * 64;
+        if ((uint32_t)c >= len) continue;
         uint32_t r = (uint32_t)c + lane;  // segment-relative position
         bool valid = r < len;
-        uint32_t t = valid ? r + adv[a + r] : 0;
-        bool done = true;
-        uint32_t val = 0, tgt = lane;
+        uint32_t t = valid ? r + av[q] : 0;
+        // one word per lane: bit 31 set = resolved, the low bits the exit; clear = the lane (of this chunk) it jumps to.
+        // A round of pointer jumping is then ONE cross-lane read -- the word of the target is either its answer or the
+        // lane two jumps on -- where value, flag and target were three (the kernel's time was their trips through the LDS
+        // crossbar)
+        uint32_t w = 0x80000000u;
         if (valid) {
             if (t >= len) {
-                val = t - len;
+                w = 0x80000000u | (t - len);
             } else if (t >= (uint32_t)c + 64) {
-                val = J[t];
+                w = 0x80000000u | J[t];
             } else {
-                done = false;
-                tgt = t - (uint32_t)c;
+                w = t - (uint32_t)c;
             }
         }
-        while (__any(!done)) {
-            uint32_t tv = __shfl(val, (int)tgt);
-            int td = __shfl((int)done, (int)tgt);
-            uint32_t tt = __shfl(tgt, (int)tgt);
-            if (!done) {
-                if (td) {
-                    val = tv;
-                    done = true;
-                } else {
-                    tgt = tt;
-                }
-            }
+        while (__any(!(w >> 31))) {
+            const uint32_t tw = (uint32_t)__shfl((int)w, (int)(w & 63u));
+            if (!(w >> 31)) w = tw;
         }
+        const uint32_t val = w & 0x7fffffffu;
         if (valid) J[r] = (uint16_t)val;
         wave_lds_fence();
     }
@@ -2051,6 +2053,13 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
     }
 }
 
+// the table with the two entries at and behind position j already in registers
+struct NearM {
+    const uint32_t* g;
+    uint64_t j;
+    uint32_t v0, v1;
+    __device__ uint32_t operator()(uint64_t i) const { return i == j ? v0 : i == j + 1 ? v1 : g[i]; }
+};
 // ---------------------------------------------------------------------------------------------
 // k_emit: walk each segment from its entry and write its tokens (output_writer.rs:47-65).
 // ---------------------------------------------------------------------------------------------
@@ -2076,7 +2085,14 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     const uint32_t len = (uint32_t)(b - a);
     uint16_t* A = s_adv[wv];
     uint16_t* P = s_pp[wv];
-    for (uint32_t r = lane; r < len; r += 64) A[r] = adv[(uint64_t)pos0 + a + r];
+    {   // (fetched together: a load per round of a loop is a memory latency per round)
+        uint16_t av[SEG / 64];
+#pragma unroll
+        for (uint32_t q = 0; q < SEG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
+#pragma unroll
+        for (uint32_t q = 0; q < SEG / 64; q++)
+            if (q * 64 + lane < len) A[q * 64 + lane] = av[q];
+    }
     wave_lds_fence();
     for (uint32_t r = lane; r < len; r += 64) {  // two steps, or one that leaves the segment
         const uint32_t t = r + A[r];
@@ -2111,7 +2127,6 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     }
     wave_lds_fence();
     const uint32_t np = s_np[wv];
-    GM m{M}, mq{Mq ? Mq : M};
     uint32_t* out = tokbuf + a;
     const uint64_t jend = (uint64_t)pos0 + b;
     uint32_t running = 0;
@@ -2120,18 +2135,34 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         const bool have = idx < np;
         uint32_t nl[4], tm[4], ntok = 0;
         uint64_t jp[4];
-        uint64_t j = have ? (uint64_t)pos0 + a + P[idx] : jend;
+        // The four positions of a lane come out of the jumps in LDS, so the table entries all four steps will look at first
+        // -- M at the position and at the one behind it, where the lazy step looks (lz77.rs:351-355) -- are fetched together:
+        // taken one parse_step after the other they were a dozen memory latencies in a row.
+        uint32_t rel = have ? (uint32_t)P[idx] : len;
+        uint32_t v0[4], v1[4], u1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool on = rel < len;
+            jp[q] = on ? (uint64_t)pos0 + a + rel : jend;
+            v0[q] = v1[q] = u1[q] = 0;
+            if (on) {
+                v0[q] = M[jp[q]];
+                v1[q] = M[jp[q] + 1];  // (the tables are padded: the entry behind the last position exists)
+                if (Mq) u1[q] = Mq[jp[q] + 1];
+                rel += A[rel];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             nl[q] = 0;
             tm[q] = 0;
-            jp[q] = j;
+            const uint64_t j = jp[q];
             if (j < jend) {
+                const NearM m{M, j, v0[q], v1[q]}, mq{Mq ? Mq : M, j, v0[q], Mq ? u1[q] : v1[q]};
                 const Step st = parse_step(m, mq, j, (uint64_t)seg_end(sg, j), cfg);
                 nl[q] = st.nlit;
                 tm[q] = st.mlen ? tok_match(st.mlen, st.mdist) : 0u;  // (never 0 for a match: dist >= 1)
                 ntok += st.nlit + (st.mlen ? 1u : 0u);
-                j += st.adv;
             }
         }
         uint32_t incl = ntok;
