@@ -1907,25 +1907,28 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 // k_adv: lz77.rs:305-547 / rle.rs:23-71 seen from a restart position: how far does the parser
 // get before it is again in a state that depends on the position only.
 // ---------------------------------------------------------------------------------------------
-// M of a workgroup's 1024 positions plus a short halo, staged in LDS: the lazy step looks one entry
-// ahead per deferral (lz77.rs:351-355), a chain of dependent reads that is cheap from LDS
-constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 64;
+// M of a workgroup's 1024 positions plus a halo, staged in LDS: the lazy step looks one entry ahead per deferral
+// (lz77.rs:351-355), a chain of dependent reads that is cheap from LDS.  The halo covers the longest chain there is: a
+// deferral needs a strictly longer match (3 .. 258), so a step reads at most 256 entries beyond its position -- no step
+// leaves the tile, the reads are plain LDS reads at 32-bit tile-relative positions (with a 64-entry halo and a fall-back
+// to global memory they were generic loads behind 64-bit selects, and the kernel was bound by its vector instructions).
+constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 260;
 struct TileM {
-    const uint32_t* g;   // the table in global memory (beyond the halo)
-    const uint32_t* t;   // the staged tile
-    uint64_t j0;         // first position of the tile
-    __device__ uint32_t operator()(uint64_t i) const {
-        const uint64_t r = i - j0;
-        return r < ADV_TILE + ADV_HALO ? t[r] : g[i];
-    }
+    const uint32_t* t;  // the staged tile
+    __device__ uint32_t operator()(uint32_t r) const { return t[r]; }
 };
+// the end of the data the encoder had at a position, relative to a base and clipped to 32 bits
+__device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, uint32_t r) {
+    const uint64_t e = (uint64_t)seg_end(sg, base + r) - base;
+    return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+}
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                              ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg, uint32_t blk0) {
     __shared__ __attribute__((aligned(16))) uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
     const uint64_t t0 = ((uint64_t)blockIdx.x + blk0) * ADV_TILE;  // (blk0: a launch may cover a range of tiles)
     const bool useq = Mq != nullptr;
     // (the tables are padded by 64 entries and 256-byte aligned, a tile starts at a multiple of 1024 entries:
-    // sixteen bytes per lane)
+    // sixteen bytes per lane; entries beyond the padding read as "no match")
     for (uint32_t i = threadIdx.x * 4; i < ADV_TILE + ADV_HALO; i += 1024) {
         const uint64_t g = t0 + i;
         uint4 v = make_uint4(0, 0, 0, 0), q = make_uint4(0, 0, 0, 0);
@@ -1947,18 +1950,20 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
     }
     __syncthreads();
     // four consecutive positions per lane, one 8-byte store of adv
-    uint64_t j0 = t0 + (uint64_t)threadIdx.x * 4;
-    if (j0 >= n) return;
-    TileM m{M, sM, t0}, mq{useq ? Mq : M, useq ? sQ : sM, t0};
+    const uint32_t r0 = threadIdx.x * 4;
+    if (t0 + r0 >= n) return;
+    const uint32_t left = (uint64_t)n - t0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n - t0);  // positions from t0
+    const uint32_t one = sg.m == 1 ? rel_end(sg, t0, 0) : 0u;  // without flush points: one end for all
+    TileM m{sM}, mq{useq ? sQ : sM};
     uint16_t a[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (j0 + q < n) a[q] = (uint16_t)parse_step(m, mq, j0 + q, (uint64_t)seg_end(sg, j0 + q), cfg).adv;
-    if (j0 + 4 <= n) {
+    for (uint32_t q = 0; q < 4; q++)
+        if (r0 + q < left) a[q] = (uint16_t)parse_step(m, mq, r0 + q, sg.m == 1 ? one : rel_end(sg, t0, r0 + q), cfg).adv;
+    if (r0 + 4 <= left) {
         uint2 v = make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
-        *reinterpret_cast<uint2*>(adv + j0) = v;  // adv is 256-byte aligned, j0 a multiple of 4
+        *reinterpret_cast<uint2*>(adv + t0 + r0) = v;  // adv is 256-byte aligned, r0 a multiple of 4
     } else {
-        for (int q = 0; q < 4 && j0 + q < n; q++) adv[j0 + q] = a[q];
+        for (uint32_t q = 0; q < 4 && r0 + q < left; q++) adv[t0 + r0 + q] = a[q];
     }
 }
 
@@ -2053,12 +2058,12 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
     }
 }
 
-// the table with the two entries at and behind position j already in registers
+// the table with the two entries at and behind position j already in registers (positions relative to `g`)
 struct NearM {
     const uint32_t* g;
-    uint64_t j;
+    uint32_t j;
     uint32_t v0, v1;
-    __device__ uint32_t operator()(uint64_t i) const { return i == j ? v0 : i == j + 1 ? v1 : g[i]; }
+    __device__ uint32_t operator()(uint32_t i) const { return i == j ? v0 : i == j + 1 ? v1 : g[i]; }
 };
 // ---------------------------------------------------------------------------------------------
 // k_emit: walk each segment from its entry and write its tokens (output_writer.rs:47-65).
@@ -2128,13 +2133,18 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     wave_lds_fence();
     const uint32_t np = s_np[wv];
     uint32_t* out = tokbuf + a;
-    const uint64_t jend = (uint64_t)pos0 + b;
+    // (32-bit positions relative to the segment's first byte: tables, input and the end of the data)
+    const uint64_t sbase = (uint64_t)pos0 + a;
+    const uint32_t* const Ms = M + sbase;
+    const uint32_t* const Mqs = (Mq ? Mq : M) + sbase;
+    const uint8_t* const ins = in + sbase;
+    const uint32_t one = sg.m == 1 ? rel_end(sg, sbase, 0) : 0u;
     uint32_t running = 0;
     for (uint32_t i0 = 0; i0 < np; i0 += 64) {
         const uint32_t idx = i0 + lane;
         const bool have = idx < np;
         uint32_t nl[4], tm[4], ntok = 0;
-        uint64_t jp[4];
+        uint32_t jp[4];  // (relative to the segment, like the tables below)
         // The four positions of a lane come out of the jumps in LDS, so the table entries all four steps will look at first
         // -- M at the position and at the one behind it, where the lazy step looks (lz77.rs:351-355) -- are fetched together:
         // taken one parse_step after the other they were a dozen memory latencies in a row.
@@ -2143,12 +2153,12 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const bool on = rel < len;
-            jp[q] = on ? (uint64_t)pos0 + a + rel : jend;
+            jp[q] = on ? rel : len;
             v0[q] = v1[q] = u1[q] = 0;
             if (on) {
-                v0[q] = M[jp[q]];
-                v1[q] = M[jp[q] + 1];  // (the tables are padded: the entry behind the last position exists)
-                if (Mq) u1[q] = Mq[jp[q] + 1];
+                v0[q] = Ms[rel];
+                v1[q] = Ms[rel + 1];  // (the tables are padded: the entry behind the last position exists)
+                if (Mq) u1[q] = Mqs[rel + 1];
                 rel += A[rel];
             }
         }
@@ -2156,10 +2166,10 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         for (int q = 0; q < 4; q++) {
             nl[q] = 0;
             tm[q] = 0;
-            const uint64_t j = jp[q];
-            if (j < jend) {
-                const NearM m{M, j, v0[q], v1[q]}, mq{Mq ? Mq : M, j, v0[q], Mq ? u1[q] : v1[q]};
-                const Step st = parse_step(m, mq, j, (uint64_t)seg_end(sg, j), cfg);
+            const uint32_t j = jp[q];
+            if (j < len) {
+                const NearM m{Ms, j, v0[q], v1[q]}, mq{Mqs, j, v0[q], Mq ? u1[q] : v1[q]};
+                const Step st = parse_step(m, mq, j, sg.m == 1 ? one : rel_end(sg, sbase, j), cfg);
                 nl[q] = st.nlit;
                 tm[q] = st.mlen ? tok_match(st.mlen, st.mdist) : 0u;  // (never 0 for a match: dist >= 1)
                 ntok += st.nlit + (st.mlen ? 1u : 0u);
@@ -2175,7 +2185,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         uint32_t* o = out + running + (incl - ntok);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            for (uint32_t x = 0; x < nl[q]; x++) o[x] = tok_literal(in[jp[q] + x]);
+            for (uint32_t x = 0; x < nl[q]; x++) o[x] = tok_literal(ins[jp[q] + x]);
             o += nl[q];
             if (tm[q]) *o++ = tm[q];
         }

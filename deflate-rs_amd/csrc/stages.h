@@ -1276,8 +1276,10 @@ MI355_HD bool match_too_far(uint32_t len, uint32_t dist) { return len == MIN_MAT
 // filter matching.rs:110,161), a becomes a literal; the chain ends by emitting the pending
 // match when it is not beaten, when it is >= lazy_if_less_than (lz77.rs:374-377: no lookahead),
 // or when a+1 has no hash byte (lz77.rs:442-468).
-template <class MT>
-MI355_HD Step parse_step(const MT& M, const MT& Mq, uint64_t j, uint64_t n, const ParseCfg& cfg) {
+// (I: the type of a position -- uint64_t for absolute ones; the kernels use 32-bit positions relative to a tile or
+// segment, with `n` relative to the same origin and the tables read through an accessor that knows it)
+template <class MT, class I>
+MI355_HD Step parse_step(const MT& M, const MT& Mq, I j, I n, const ParseCfg& cfg) {
     Step s;
     s.nlit = 0;
     s.mlen = 0;
@@ -1311,7 +1313,7 @@ MI355_HD Step parse_step(const MT& M, const MT& Mq, uint64_t j, uint64_t n, cons
         s.adv = L;
         return s;
     }
-    uint64_t a = j;
+    I a = j;
     for (;;) {
         if (L >= cfg.lazy_lt) break;   // ignore_next (lz77.rs:374-377,380-386)
         if (a + 1 + 2 >= n) break;     // a+1 has no hash byte (lz77.rs:442-468)
