@@ -2022,24 +2022,30 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
 }
 
 // k_level_up: compose FAN child tables into one parent table.
-__global__ __launch_bounds__(256) void k_level_up(uint32_t n, uint32_t nc, uint64_t csize,
-                                                  const uint16_t* __restrict__ C, uint32_t nu,
-                                                  uint16_t* __restrict__ X) {
-    uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (uint64_t)nu * ZONE) return;
-    uint64_t u = gid / ZONE;
-    uint32_t e = (uint32_t)(gid % ZONE);
-    uint64_t usize = csize * FAN;
-    uint64_t ustart = u * usize;
-    uint64_t uend = ustart + usize < n ? ustart + usize : n;
-    uint64_t pos = ustart + e;
-    uint64_t c1 = (u + 1) * FAN < nc ? (u + 1) * FAN : nc;
-    for (uint64_t c = u * FAN; c < c1; c++) {
-        uint64_t cstart = c * csize;
-        uint64_t cend = cstart + csize < n ? cstart + csize : n;
-        if (pos < cend) pos = cend + C[c * ZONE + (pos - cstart)];
+// A workgroup per parent unit, a thread per entry of its zone.  The FAN child tables (one contiguous piece of C) are
+// staged in LDS first, every thread fetching its FAN entries at once: an entry's way through the children is a chain of
+// FAN dependent reads, which from global memory was FAN memory latencies per launch (52 us at the widest level).
+// Positions are 32-bit and relative to the child at hand.
+__global__ __launch_bounds__(ZONE) void k_level_up(uint32_t n, uint32_t nc, uint64_t csize,
+                                                   const uint16_t* __restrict__ C, uint32_t nu,
+                                                   uint16_t* __restrict__ X) {
+    __shared__ uint16_t sC[FAN][ZONE];
+    const uint32_t u = blockIdx.x, e = threadIdx.x;
+    const uint32_t c0 = u * FAN, c1 = c0 + FAN < nc ? c0 + FAN : nc;
+    uint16_t v[FAN];
+#pragma unroll
+    for (uint32_t k = 0; k < FAN; k++) v[k] = c0 + k < c1 ? C[(uint64_t)(c0 + k) * ZONE + e] : (uint16_t)0;
+#pragma unroll
+    for (uint32_t k = 0; k < FAN; k++) sC[k][e] = v[k];
+    __syncthreads();
+    uint32_t rel = e;  // the entry's position, relative to the start of child k
+    for (uint32_t k = 0; k < c1 - c0; k++) {
+        const uint64_t cstart = (uint64_t)(c0 + k) * csize;
+        const uint32_t sz = (uint64_t)n - cstart < csize ? (uint32_t)((uint64_t)n - cstart) : (uint32_t)csize;  // (csize <= 2^32: a level's units tile a 32-bit input)
+        if (rel < sz) rel = sz + sC[k][rel];
+        rel -= sz;
     }
-    X[gid] = (uint16_t)(pos - uend);
+    X[(uint64_t)u * ZONE + e] = (uint16_t)rel;  // relative to the end of the unit
 }
 
 // k_level_down: given the entry position of every parent unit, the entry of each child.

@@ -1,5 +1,5 @@
 """Debug aid (GPU box): counters and clock shares of k_match3 from an instrumented build (-DMI355_MATCH_STATS
--DMI355_MATCH_PATH_DEFAULT=4, deflate-rs_amd/variants/libstats3.so).  usage: match3_stats.py [bytes] [level]"""
+-DMI355_MATCH_PATH_DEFAULT=4, deflate-rs_amd/variants/libstats3.so).  usage: match3_stats.py [bytes] [level] [text|silesia]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MI355_DEFLATE_LIB"] = os.environ.get("MI355_STATS_LIB", os.path.join(ROOT, "deflate-rs_amd", "variants", "libstats3.so"))
@@ -8,7 +8,8 @@ import datagen, deflate_amd as da
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 level = sys.argv[2] if len(sys.argv) > 2 else "default"
 lv = {"default": da.Compression.Default, "best": da.Compression.Best, "fast": da.Compression.Fast}[level]
-data = datagen.text_like(n, 0x656E)
+data = datagen.silesia_like(scale=n / 212.1e6) if (len(sys.argv) > 3 and sys.argv[3] == "silesia") else datagen.text_like(n, 0x656E)
+n = len(data)
 ctx = da.Context(0)
 L = da.load()
 out = (C.c_ulonglong * 16)()
