@@ -1,7 +1,7 @@
 """Debug aid (GPU box): clock shares of the phases of k_sort (instrumented build, MI355_MATCH_PATH must select the sorted path)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MI355_DEFLATE_LIB"] = os.path.join(ROOT, "deflate-rs_amd", "variants", "libstats.so")
+os.environ["MI355_DEFLATE_LIB"] = os.environ.get("MI355_STATS_LIB", os.path.join(ROOT, "deflate-rs_amd", "variants", "libstats.so"))
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datagen, deflate_amd as da
 n = 20_000_000
