@@ -1096,6 +1096,11 @@ __device__ __forceinline__ const uint16_t* uniform_ptr(const uint16_t* p) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
+__device__ __forceinline__ uint64_t uniform_mask(uint64_t m) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 #define MS_STEPS(NAME, BODY, OPS8, ...)                                                                                       \
     template <bool HAS_Q>                                                                                                     \
     __device__ __forceinline__ uint64_t NAME(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {                             \
@@ -1127,7 +1132,7 @@ MS_STEPS(ms_steps_key4, MS_BODY4("ds_read_u8"), MS_OPS4)
 #ifndef MI355_M3_DUAL
 #define MI355_M3_DUAL 1
 #endif
-static_assert(!MI355_M3_DUAL || MI355_M3_W == 8, "two fibres walk in groups of eight");
+static_assert(!MI355_M3_DUAL || MI355_M3_W == 8, "two fibres walk in groups of eight");  // (MI355_M3_DUAL = 2: with refill)
 #ifndef MI355_M4_W
 #define MI355_M4_W 4
 #endif
@@ -1211,10 +1216,12 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     MF_CMP(F, N3, "t4") MF_CMP(F, N2, "t5") MF_CMP(F, N1, "t6") MF_CMP(F, N0, "t7")                                \
     "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
     "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+// (addresses and answers are written before they are read by every lane that walks: plain outputs, so none of a fibre's
+// sixteen stays live between its service and its next step block)
 #define MF_OPS(F, S)                                                                                                        \
-    [F##offb] "+v"(S.offb), [F##a0] "+v"(S.a0), [F##a1] "+v"(S.a1), [F##a2] "+v"(S.a2), [F##a3] "+v"(S.a3), [F##a4] "+v"(S.a4), \
-    [F##a5] "+v"(S.a5), [F##a6] "+v"(S.a6), [F##a7] "+v"(S.a7), [F##t0] "+v"(S.t0), [F##t1] "+v"(S.t1), [F##t2] "+v"(S.t2), \
-    [F##t3] "+v"(S.t3), [F##t4] "+v"(S.t4), [F##t5] "+v"(S.t5), [F##t6] "+v"(S.t6), [F##t7] "+v"(S.t7)
+    [F##offb] "+v"(S.offb), [F##a0] "=&v"(S.a0), [F##a1] "=&v"(S.a1), [F##a2] "=&v"(S.a2), [F##a3] "=&v"(S.a3), [F##a4] "=&v"(S.a4), \
+    [F##a5] "=&v"(S.a5), [F##a6] "=&v"(S.a6), [F##a7] "=&v"(S.a7), [F##t0] "=&v"(S.t0), [F##t1] "=&v"(S.t1), [F##t2] "=&v"(S.t2), \
+    [F##t3] "=&v"(S.t3), [F##t4] "=&v"(S.t4), [F##t5] "=&v"(S.t5), [F##t6] "=&v"(S.t6), [F##t7] "=&v"(S.t7)
 #define MF_INS(F, S) [F##bb] "v"(S.bb2), [F##lowa] "v"(S.lowa2), [F##probe] "v"(S.probe), [F##endb] "v"(S.endb)
 
 template <bool HAS_Q>
@@ -1271,6 +1278,34 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
     *stilly = cy;
 }
 
+// the end of an epoch's walk (a macro: the loops above end in it)
+#define MI355_M3_UNPERMUTE \
+    if (Ms) { \
+ /* The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position */ \
+ /* they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for */ \
+ /* 0.4 GB of M).  Now that the walk is over the pair table is not needed any more: its LDS takes the epoch's */ \
+ /* results by position, and they leave as whole lines. */ \
+        uint32_t* const lm = reinterpret_cast<uint32_t*>(s_T); \
+        const uint32_t cnt = (uint32_t)((uint64_t)n - E < (uint64_t)WINDOW_SIZE ? (uint64_t)n - E : (uint64_t)WINDOW_SIZE); \
+        for (int pass = 0; pass < (HAS_Q ? 2 : 1); pass++) { \
+            const uint32_t* src = pass ? Mqs : Ms; \
+            uint32_t* dst = pass ? Mq : M; \
+            __syncthreads(); \
+            for (uint32_t j = tid; j < J; j += M3T) lm[(uint32_t)own[j] >> 1] = src[E + j]; \
+            if (tid < 2 && J + tid < cnt) lm[J + tid] = 0; /* the positions without a hash byte */ \
+            __syncthreads(); \
+            for (uint32_t i = tid * 4; i < cnt; i += M3T * 4) { \
+                if (i + 4 <= cnt) { \
+                    *reinterpret_cast<uint4*>(dst + E + i) = *reinterpret_cast<const uint4*>(lm + i); \
+                } else { \
+                    for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k]; \
+                } \
+            } \
+        } \
+    }
+#ifndef MI355_M3_T
+#define MI355_M3_T 16
+#endif
 template <bool HAS_Q>
 __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
@@ -1372,7 +1407,297 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             swg_service(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
         }
     };
-#if MI355_M3_DUAL
+#if MI355_M3_DUAL >= 2
+    // ---- lanes that take a new position when they have finished theirs (MI355_M3_DUAL=2; 3: one fibre per wave) ----------------------------
+    // A batch needs as many services as its busiest lane has events, and its tail walks with a few lanes: so a fibre is not
+    // a batch any more.  The next two batches are set up densely (64 lanes) and PARKED, twelve bytes per position, in the
+    // LDS the pair table leaves (slots A and B of the wave): srel | bucket bounds | first candidate.  A lane of either
+    // fibre that has finished takes the record of ITS lane number out of a slot (so lane l only ever works on entries
+    // l, l + 64, ... of the batches that pass), stores the result it holds, and is set up from the record -- once enough
+    // lanes of the fibre wait (MI355_M3_T) or nothing of it walks; its first candidate rides with the fibre's next service.
+    // A slot that is used up is parked anew, one phase per round of the loop, so that each phase's loads have a step
+    // block and two services to arrive in.
+    __shared__ uint32_t s_park[M3T / 64][2][3][64];
+    uint32_t* const Mo = Ms ? Ms : M;
+    uint32_t* const Mqo = Ms ? Mqs : Mq;
+    uint32_t* const pk = &s_park[tid >> 6][0][0][0];
+    const uint16_t* const sprev = own - WINDOW_SIZE;
+    // the pool is a queue: records qh .. qt - 1 wait, record i lies in slot (i / 64) % 2 at place i % 64; only the last
+    // batch of an epoch can be short, so every other one fills its 64 places
+    uint32_t qh = 0, qt = 0;
+    uint32_t batA = 0, batB = 0;    // the batch in slot 0 / 1
+    bool more = true;               // batches left to hand out
+    uint32_t ph = 0, qb = 0;        // the parking in progress: phase, batch, and what is in flight
+    uint32_t q_own = 0, q_prev = 0, q_ob = 0, q_pb0 = 0, q_pb1 = 0, q_first = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+        const uint32_t j = qb * 64 + lane;
+        const bool qv = j < J;
+        if (ph == 3) {
+            const uint32_t slot = (qt >> 6) & 1u;
+            uint32_t* const r = pk + slot * 192u + lane;
+            r[0] = q_own >> 1;
+            r[64] = q_ob | (q_pb0 << 16);
+            r[128] = q_pb1 | (q_first << 16);
+            if (slot == 0)
+                batA = qb;
+            else
+                batB = qb;
+            qt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(qv));
+            if (qt & 63u) more = false;  // (a short batch is the epoch's last)
+            wave_lds_fence();
+            ph = 0;
+        }
+        if (ph == 0) {
+            // (a slot is free once the queue's head has left it)
+            if (!more || qt - qh > 64u) return;
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&s_next, 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b >= b_hi) {
+                more = false;
+                return;
+            }
+            qb = b;
+            const uint32_t jn = b * 64 + lane;
+            q_own = jn < J ? (uint32_t)own[jn] : 0u;
+            q_prev = (jn < J && jn > 0) ? (uint32_t)own[jn - 1] : 0u;
+            M2_CNT(0, 1)
+            ph = 1;
+        } else if (ph == 1) {
+            const uint32_t srel = q_own >> 1;
+            const uint32_t v = win.load32(bias + srel);
+            const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
+            const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
+            q_ob = q_pb0 = q_pb1 = 0;
+            if (qv) {
+                q_ob = Bown[h];
+                if (e) {
+                    q_pb0 = Bprev[h];
+                    q_pb1 = Bprev[h + 1];
+                }
+            }
+            ph = 2;
+        } else {
+            // the first candidate: the entry before the lane's own in its bucket, else the last of the previous epoch's bucket
+            q_first = q_prev;
+            if (qv && j <= q_ob && q_pb1 > q_pb0) q_first = sprev[q_pb1 - 1];
+            ph = 3;
+        }
+    };
+    // Idle lanes `idle` of a fibre take the records at the head of the queue, in lane order: each stores the result it
+    // holds and is set up from its record.  Returns those with candidates: they "left at the first probe of a group" and
+    // go to the fibre's next service.
+    auto refill = [&](SwG<HAS_Q>& st, uint32_t& cur, uint32_t& fa, uint64_t idle) __attribute__((always_inline)) -> uint64_t {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const uint32_t avail = qt - qh;
+        const bool tk = __builtin_amdgcn_inverse_ballot_w64(idle) && rank < avail;
+        const uint64_t take = uniform_mask(__builtin_amdgcn_ballot_w64(tk));
+#ifndef MI355_M3_NOSTORE
+        {
+            uint32_t pm, pq;
+            swg_result(st, &pm, &pq);
+            if (tk && cur != ~0u) {
+                Mo[E + cur] = pm;
+                if (HAS_Q) Mqo[E + cur] = pq;
+            }
+        }
+#endif
+        const uint32_t idx = qh + rank;
+        const bool inA = ((idx >> 6) & 1u) == 0;
+        const uint32_t* const r = pk + (inA ? 0u : 192u) + (idx & 63u);
+        uint32_t r0 = 0, r1 = 0, r2 = 0;
+        if (tk) {
+            r0 = r[0];
+            r1 = r[64];
+            r2 = r[128];
+        }
+        const uint32_t jb = (inA ? batA : batB) * 64 + (idx & 63u);
+        uint32_t prel = bias, nrel = bias;  // (a lane that takes nothing: nothing to search)
+        if (tk) {
+            prel = bias + r0;
+            nrel = lim(prel);
+        }
+        SwG<HAS_Q> nw;
+        (void)swg_setup(nw, win, tk ? jb : 0u, r1 & 0xffffu, r1 >> 16, r2 & 0xffffu, prel, nrel, tbase, bias, checks, checks_q);
+        const uint64_t fst = uniform_mask(nw.walk & take);
+        const bool fs = __builtin_amdgcn_inverse_ballot_w64(fst);
+#define MI355_MRG(F) st.F = tk ? nw.F : st.F;
+        MI355_MRG(offb) MI355_MRG(endb) MI355_MRG(bb2) MI355_MRG(lowa2) MI355_MRG(probe) MI355_MRG(prel) MI355_MRG(maxlen)
+        MI355_MRG(p16[0]) MI355_MRG(p16[1]) MI355_MRG(p16[2]) MI355_MRG(p16[3]) MI355_MRG(bm1) MI355_MRG(bestd) MI355_MRG(low)
+        MI355_MRG(offb2) MI355_MRG(endb2) MI355_MRG(seg0) MI355_MRG(vbase) MI355_MRG(mq)
+#undef MI355_MRG
+        fa = fs ? (r2 >> 16) + st.bb2 : fa;  // (the probe address of the first candidate; its entry is the one at offb)
+        // (wave-uniform all of them, which the compiler does not see: as lane values they would live in vector registers)
+        st.walk = uniform_mask(st.walk & ~take);
+        st.done = uniform_mask((st.done & ~take) | (~nw.walk & take));
+        st.in_prev = uniform_mask((st.in_prev & ~take) | (nw.in_prev & take));
+        st.hq = uniform_mask((st.hq & ~take) | (nw.hq & take));
+        st.has2 = uniform_mask((st.has2 & ~take) | (nw.has2 & take));
+        cur = tk ? (Ms ? jb : r0) : cur;
+        qh += (uint32_t)__popcll(take);
+        M2_T(8)
+        return fst;
+    };
+    SwG<HAS_Q> sx, sy;
+    {
+        SwG<HAS_Q> z;
+        (void)swg_setup(z, win, 0u, 0u, 0u, 0u, bias, bias, tbase, bias, checks, checks_q);  // a fibre without positions
+        z.walk = 0;
+        z.done = ~0ull;
+        sx = z;
+        sy = z;
+    }
+    uint32_t curx = ~0u, cury = ~0u, fax = 0, fay = 0;
+    // What a fibre's service needs of the lanes that left the last block and of those set up since the last service (their
+    // first candidate has "left at a probe"): read off the probe answers of BOTH fibres before either is served, so that
+    // neither fibre's sixteen are live during a service.
+    auto decode2 = [&](SwG<HAS_Q>& st, uint64_t dropped, uint64_t first, uint32_t fa, uint64_t* hits, uint32_t* asel_out,
+                       uint32_t* ho_out) __attribute__((always_inline)) {
+        uint64_t any;
+        uint32_t asel, back;
+        ms_decode<MI355_M3_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
+                                      st.a6, st.a7, st.probe},
+                              &any, &asel, &back);
+        const bool pf = __builtin_amdgcn_inverse_ballot_w64(first);
+        *asel_out = pf ? fa : asel;
+        *ho_out = st.offb + (pf ? 0u : back);
+        *hits = uniform_mask((any & dropped) | first);
+    };
+    auto serve2 = [&](SwG<HAS_Q>& st, uint64_t all, uint64_t hits, uint32_t asel, uint32_t ho) __attribute__((always_inline)) {
+        if (hits | (all & st.has2)) {
+            M2_CNT(2, 1)
+            M2_CNT(3, __popcll(all))
+            swg_service(st, win, tbase, checks_q, all, hits, asel, ho);
+        }
+    };
+    // the first two batches are parked before anything walks
+    do advance(); while (ph != 0 || (more && qt - qh <= 64u));
+#if MI355_M3_DUAL == 3
+    (void)sy;
+    (void)cury;
+    (void)fay;
+    for (;;) {
+        sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);
+        sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);
+        qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);
+        qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
+        const uint64_t wx = sx.walk;
+        uint64_t dx = 0;
+        if (wx) {
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(wx))
+            const uint64_t cx = ms_steps_pair8(sx, sbase - 4, wx);
+            M2_T(12)
+            sx.walk = cx;
+            dx = wx & ~cx;
+        }
+        uint64_t hx = 0;
+        uint32_t ax = 0, ox = 0;
+        if (dx) decode2(sx, dx, 0, 0u, &hx, &ax, &ox);
+        advance();
+        uint64_t fx = 0;
+        {
+            const uint64_t t = ~(sx.walk | dx);
+            const uint32_t av = qt - qh;
+            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
+                fx = refill(sx, curx, fax, t);
+                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fx);
+                ax = pf ? fax : ax;
+                ox = pf ? sx.offb : ox;
+            }
+        }
+        sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);
+        sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);
+        qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);
+        qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
+        fx = uniform_mask(fx);
+        hx = uniform_mask(hx);
+        if (dx | fx) serve2(sx, dx | fx, hx | fx, ax, ox);
+        M2_T(9)
+        if (sx.walk == 0 && !more && ph == 0 && qt == qh) break;
+    }
+#else
+#define MI355_UNI_MASKS                                                                                             \
+    sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);        \
+    sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);                                                   \
+    sy.walk = uniform_mask(sy.walk); sy.done = uniform_mask(sy.done); sy.in_prev = uniform_mask(sy.in_prev);        \
+    sy.hq = uniform_mask(sy.hq); sy.has2 = uniform_mask(sy.has2);                                                   \
+    qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);                                                         \
+    qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
+    for (;;) {
+        // (the lane masks are wave-uniform, which the compiler loses sight of around the loop and behind a conditional
+        // refill: as lane values they would live in vector registers, two each)
+        MI355_UNI_MASKS
+        const uint64_t wx = sx.walk, wy = sy.walk;
+        uint64_t dx = 0, dy = 0;
+        if (wx | wy) {
+            M2_CNT(1, 1)
+            M2_CNT(7, __popcll(wx) + __popcll(wy))
+            uint64_t cx, cy;
+            ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
+            M2_T(12)
+            sx.walk = cx;
+            sy.walk = cy;
+            dx = wx & ~cx;
+            dy = wy & ~cy;
+        }
+        uint64_t hx = 0, hy = 0;
+        uint32_t ax = 0, ay = 0, ox = 0, oy = 0;
+        if (dx) decode2(sx, dx, 0, 0u, &hx, &ax, &ox);
+        if (dy) decode2(sy, dy, 0, 0u, &hy, &ay, &oy);
+        // Parking and refill come here: no group of probes is live any more, and what they load and store has the two
+        // services to arrive in (the step block's waits count every memory operation of the wave).
+        advance();
+        uint64_t fx = 0, fy = 0;
+        {
+            const uint64_t t = ~(sx.walk | dx);
+            const uint32_t av = qt - qh;  // (a refill for a handful of records is not worth its price unless they are the last)
+            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
+                fx = refill(sx, curx, fax, t);
+                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fx);
+                ax = pf ? fax : ax;
+                ox = pf ? sx.offb : ox;
+            }
+        }
+        {
+            const uint64_t t = ~(sy.walk | dy);
+            const uint32_t av = qt - qh;
+            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
+                fy = refill(sy, cury, fay, t);
+                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fy);
+                ay = pf ? fay : ay;
+                oy = pf ? sy.offb : oy;
+            }
+        }
+        MI355_UNI_MASKS
+        fx = uniform_mask(fx);
+        fy = uniform_mask(fy);
+        hx = uniform_mask(hx);
+        hy = uniform_mask(hy);
+        if (dx | fx) serve2(sx, dx | fx, hx | fx, ax, ox);
+        if (dy | fy) serve2(sy, dy | fy, hy | fy, ay, oy);
+        M2_T(9)
+        if ((sx.walk | sy.walk) == 0 && !more && ph == 0 && qt == qh) break;
+    }
+#undef MI355_UNI_MASKS
+#endif
+#ifndef MI355_M3_NOSTORE
+    {
+        uint32_t pm, pq;
+        swg_result(sx, &pm, &pq);
+        if (curx != ~0u) {
+            Mo[E + curx] = pm;
+            if (HAS_Q) Mqo[E + curx] = pq;
+        }
+        swg_result(sy, &pm, &pq);
+        if (cury != ~0u) {
+            Mo[E + cury] = pm;
+            if (HAS_Q) Mqo[E + cury] = pq;
+        }
+    }
+    MI355_M3_UNPERMUTE
+#endif
+#elif MI355_M3_DUAL
     uint32_t* const Mo = Ms ? Ms : M;      // where a batch's results go: in the order of S_e (turned round at the end), else by position
     uint32_t* const Mqo = Ms ? Mqs : Mq;
     uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
@@ -1438,29 +1763,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         Mo[E + pyat] = pym;
         if (HAS_Q) Mqo[E + pyat] = pyq;
     }
-    if (Ms) {
-        // The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position
-        // they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for
-        // 0.4 GB of M).  Now that the walk is over the pair table is not needed any more: its LDS takes the epoch's
-        // results by position, and they leave as whole lines.
-        uint32_t* const lm = reinterpret_cast<uint32_t*>(s_T);
-        const uint32_t cnt = (uint32_t)((uint64_t)n - E < (uint64_t)WINDOW_SIZE ? (uint64_t)n - E : (uint64_t)WINDOW_SIZE);
-        for (int pass = 0; pass < (HAS_Q ? 2 : 1); pass++) {
-            const uint32_t* src = pass ? Mqs : Ms;
-            uint32_t* dst = pass ? Mq : M;
-            __syncthreads();
-            for (uint32_t j = tid; j < J; j += M3T) lm[(uint32_t)own[j] >> 1] = src[E + j];
-            if (tid < 2 && J + tid < cnt) lm[J + tid] = 0;  // the positions without a hash byte
-            __syncthreads();
-            for (uint32_t i = tid * 4; i < cnt; i += M3T * 4) {
-                if (i + 4 <= cnt) {
-                    *reinterpret_cast<uint4*>(dst + E + i) = *reinterpret_cast<const uint4*>(lm + i);
-                } else {
-                    for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k];
-                }
-            }
-        }
-    }
+    MI355_M3_UNPERMUTE
 #endif
 #else
     uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
