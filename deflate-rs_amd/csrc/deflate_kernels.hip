@@ -2298,7 +2298,7 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
         uint32_t r = (uint32_t)c + lane;  // segment-relative position
         bool valid = r < len;
         uint32_t t = valid ? r + av[q] : 0;
-        // one word per lane: bit 31 set = resolved, the low bits the exit; clear = the lane (of this chunk) it jumps to.
+        // one word per lane: bit 31 set = resolved, the low bits the exit; clear = the lane (of this chunk) it jumps to, times 4.
         // A round of pointer jumping is then ONE cross-lane read -- the word of the target is either its answer or the
         // lane two jumps on -- where value, flag and target were three (the kernel's time was their trips through the LDS
         // crossbar)
@@ -2309,12 +2309,12 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
             } else if (t >= (uint32_t)c + 64) {
                 w = 0x80000000u | J[t];
             } else {
-                w = t - (uint32_t)c;
+                w = (t - (uint32_t)c) << 2;  // (kept as the byte address ds_bpermute wants)
             }
         }
-        while (__any(!(w >> 31))) {
-            const uint32_t tw = (uint32_t)__shfl((int)w, (int)(w & 63u));
-            if (!(w >> 31)) w = tw;
+        while (__any((int32_t)w >= 0)) {
+            const uint32_t tw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)w, (int)w);  // (a resolved lane's read is not used)
+            w = (int32_t)w >= 0 ? tw : w;
         }
         const uint32_t val = w & 0x7fffffffu;
         if (valid) J[r] = (uint16_t)val;
