@@ -12,7 +12,9 @@ N GiB web-text input (generated per 1 MiB segment, so a rank makes exactly its o
 
 Besides the contract's fields the line carries: value_host_api (the drop-in call on pinned host buffers,
 H2D and D2H inside the timed region), roofline.input_load (achieved HBM GB/s of the kernel that reads
-the input coalesced) and roofline.lds_bank_conflict_rate of the match compare (committed PMC file),
+the input coalesced), roofline.lds_bank_conflict_rate of the match compare and roofline.valu_issue (wave
+instructions per input byte and the share of the SIMDs' cycles they take: what the dominant kernel is bound
+by; both from the committed PMC file),
 cpu_baseline as the median of five runs with its all-cores and zlib companions.
 """
 import argparse
@@ -269,6 +271,7 @@ def main():
         traffic = None
         lds_conflict = None
         pmc_source = None
+        valu_issue = None
         try:
             import glob
             cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -282,6 +285,12 @@ def main():
                 traffic = k["hbm_bytes"]
                 lds_conflict = k.get("lds_bank_conflict_rate")
                 pmc_source = os.path.relpath(cands[-1], ROOT)
+                # what the kernel is really bound by (the contract's "bound" knows hbm and mfma only): vector-ALU issue.
+                # A wave64 instruction holds its SIMD for four cycles; busy = issued wave instructions x 4 over the cycles
+                # of the chip's 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                if k.get("SQ_ACTIVE_INST_VALU") and k.get("GRBM_GUI_ACTIVE"):
+                    valu_issue = {"wave_instr_per_input_byte": k.get("valu_wave_instr_per_input_byte"),
+                                  "busy": round(k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0), 3)}
         except Exception:
             pass
         # the kernel that reads the input coalesced: k_sort files every position under its hash (reads n, writes
@@ -315,7 +324,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes,
-                         "input_load": input_load, "lds_bank_conflict_rate": lds_conflict, "pmc_source": pmc_source},
+                         "input_load": input_load, "lds_bank_conflict_rate": lds_conflict, "valu_issue": valu_issue,
+                         "pmc_source": pmc_source},
         }
         if p1_trace is not None:
             res["p1_phases_ms_rank0"] = p1_trace  # (one untimed step, synchronised per phase)
