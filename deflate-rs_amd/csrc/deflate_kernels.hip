@@ -591,6 +591,122 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
     KS_T(stat0 + 2)
 }
 
+// The same pass with the rank of a key taken from the LDS itself: ds_add_rtn on the (wave, digit) counter returns how
+// many of the wave's keys with that digit came before -- batches are instructions in program order, and within one
+// instruction the LDS serves the lanes that hit one address in lane order.  That order is what the hardware does, not
+// what the ISA manual promises: k_lds_order_test checks it on the device when a context is made, and a device that fails
+// it sorts with sort_pass (ranks from ballots: 8 + 7 ballots per batch of 64 keys were half of k_sort's instructions).
+// A batch whose keys all share one digit (a run of one byte) takes its ranks from the lane number: 64 atomics on one
+// counter would be served one after the other.
+template <int NB, class Dig, class Pay, class Put>
+__device__ __forceinline__ void sort_pass_rtn(uint32_t J, uint32_t* cnt /*16 * 256*/, uint32_t* red, Dig dig, Pay pay, Put put,
+                                              unsigned long long& ks_t, int stat0) {
+    constexpr uint32_t ND = 1u << NB;
+    constexpr int NBAT = SORT_CHUNK / 64;  // batches per wave
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* mine = cnt + wv * 256;
+    for (uint32_t k = lane; k < 256; k += 64) mine[k] = 0;
+    wave_lds_fence();
+    const uint32_t cb = wv * SORT_CHUNK;
+    uint32_t dc[NBAT / 4];  // digits, four per register
+    uint32_t rk[NBAT / 2];  // rank among the wave's keys of the digit (< 2048) | valid << 15, two per register
+    uint32_t Jc = J;
+    asm volatile("" : "+s"(Jc));  // (see sort_pass)
+#pragma unroll
+    for (int b = 0; b < NBAT; b++) {
+        const uint32_t i = cb + 64 * b + lane;
+        const bool valid = i < Jc;
+        const uint32_t d = valid ? dig(i) : 0u;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
+        uint32_t r = 0;
+        if (__builtin_amdgcn_ballot_w64(valid && d != d0) == 0) {  // one digit (lane 0 is valid whenever any lane is)
+            const uint32_t nv = (uint32_t)__popcll(vm);
+            uint32_t at = 0;
+            if (nv) at = mine[d0];
+            wave_lds_fence();
+            r = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+            if (lane == 0 && nv) mine[d0] = at + nv;
+            wave_lds_fence();
+        } else if (valid) {
+            r = atomicAdd(&mine[d], 1u);
+        }
+        if ((b & 3) == 0)
+            dc[b >> 2] = d;
+        else
+            dc[b >> 2] |= d << (8 * (b & 3));
+        const uint32_t pk = r | (valid ? 0x8000u : 0u);
+        if ((b & 1) == 0)
+            rk[b >> 1] = pk;
+        else
+            rk[b >> 1] |= pk << 16;
+        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    KS_T(stat0)
+    // offsets in (digit, wave) order: thread t takes digit t / 4, waves 4 * (t % 4) ..+3
+    uint32_t v[4] = {0, 0, 0, 0}, sum = 0;
+    const uint32_t d4 = tid >> 2, w4 = (tid & 3) * 4;
+    if (d4 < ND) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = cnt[(w4 + k) * 256 + d4];
+            sum += v[k];
+        }
+    }
+    uint32_t base = block_excl_scan_1024(sum, red, nullptr);
+    if (d4 < ND) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            cnt[(w4 + k) * 256 + d4] = base;
+            base += v[k];
+        }
+    }
+    __syncthreads();
+    KS_T(stat0 + 1)
+#pragma unroll
+    for (int b = 0; b < NBAT; b++) {
+        const uint32_t i = cb + 64 * b + lane;
+        const uint32_t d = (dc[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const uint32_t pk = (rk[b >> 1] >> (16 * (b & 1))) & 0xffffu;
+        if (pk & 0x8000u) put(mine[d] + (pk & 0x7fffu), pay(i));
+    }
+    __syncthreads();
+    KS_T(stat0 + 2)
+}
+
+// Does the LDS serve the lanes of one ds_add_rtn that hit the same address in lane order?  (sort_pass_rtn)  Sixteen waves of
+// a workgroup hammer their counters with digit patterns of every kind at once -- one digit, two, few, many, random -- and
+// compare what comes back with the rank counted from ballots.  *bad counts the lanes that differ.
+__global__ __launch_bounds__(1024) void k_lds_order_test(uint32_t rounds, uint32_t* bad) {
+    __shared__ uint32_t sCnt[16 * 256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* mine = sCnt + wv * 256;
+    for (uint32_t k = lane; k < 256; k += 64) mine[k] = 0;
+    __syncthreads();
+    uint32_t x = (blockIdx.x * 1024 + tid) * 2654435761u + 12345u, wrong = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t kind = (r + wv) & 7u;
+        const uint32_t mask = kind == 0 ? 0u : kind == 1 ? 1u : kind == 2 ? 3u : kind == 3 ? 7u : kind == 4 ? 15u : kind == 5 ? 63u : 255u;
+        uint32_t d = (x >> 13) & mask;
+        if (kind == 7) d = (lane >> 2) & 255u;  // runs of four
+        const bool valid = ((x >> 5) & 15u) != 0 || kind < 2;
+        uint32_t plo, phi;
+        wave_match<8>(d, valid, &plo, &phi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        uint32_t before = 0;
+        if (valid) before = mine[d];
+        wave_lds_fence();
+        uint32_t got = 0;
+        if (valid) got = atomicAdd(&mine[d], 1u);
+        wave_lds_fence();
+        if (valid && got != before + below) wrong++;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+template <bool RTN>
 __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
                                                uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl) {
     __shared__ __attribute__((aligned(16))) uint16_t sH[WINDOW_SIZE];  // hashes; the sorted array at the end
@@ -684,6 +800,14 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     __syncthreads();
     KS_T(1)
     uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
+    if (RTN) {
+        sort_pass_rtn<8>(
+            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
+            [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2);
+        sort_pass_rtn<7>(
+            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
+            [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
+    } else {
     sort_pass<8>(
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
         [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2);
@@ -692,6 +816,7 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     sort_pass<7>(
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
         [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
+    }
     uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
     const uint4* fin = reinterpret_cast<const uint4*>(sH);
     // dbl = 1: entries as 2 * position (k_match3 adds them to a pair-table address); positions are below 32768,
@@ -1278,6 +1403,16 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
     *stilly = cy;
 }
 
+constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 260;
+struct TileM {
+    const uint32_t* t;  // the staged tile
+    __device__ uint32_t operator()(uint32_t r) const { return t[r]; }
+};
+// the end of the data the encoder had at a position, relative to a base and clipped to 32 bits
+__device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, uint32_t r) {
+    const uint64_t e = (uint64_t)seg_end(sg, base + r) - base;
+    return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
+}
 // the end of an epoch's walk (a macro: the loops above end in it)
 #define MI355_M3_UNPERMUTE \
     if (Ms) { \
@@ -1301,6 +1436,26 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
                     for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k]; \
                 } \
             } \
+ /* The epoch's table lies in LDS by position: the restart steps (k_adv, lz77.rs:305-547) of its positions are taken */ \
+ /* here, where the table costs an LDS read and the vector ALUs wait for the stores -- all but the last ADV_HALO */ \
+ /* positions of an epoch that has a successor (a step looks at most that far ahead): k_adv_tail does those. */ \
+            if (!HAS_Q && advg) { \
+                const bool last_ep = E + cnt >= (uint64_t)n; \
+                const uint32_t upto = last_ep ? cnt : (cnt > ADV_HALO ? cnt - ADV_HALO : 0u); \
+                const uint32_t one = sg.m == 1 ? rel_end(sg, E, 0) : 0u; \
+                const TileM tm{lm}; \
+                for (uint32_t i = tid * 4; i < upto; i += M3T * 4) { \
+                    uint16_t a4[4] = {0, 0, 0, 0}; \
+                    _Pragma("unroll") \
+                    for (uint32_t q = 0; q < 4; q++) \
+                        if (i + q < upto) a4[q] = (uint16_t)parse_step(tm, tm, i + q, sg.m == 1 ? one : rel_end(sg, E, i + q), pcfg).adv; \
+                    if (i + 4 <= upto) { \
+                        *reinterpret_cast<uint2*>(advg + E + i) = make_uint2((uint32_t)a4[0] | ((uint32_t)a4[1] << 16), (uint32_t)a4[2] | ((uint32_t)a4[3] << 16)); \
+                    } else { \
+                        for (uint32_t q = 0; q < 4 && i + q < upto; q++) advg[E + i + q] = a4[q]; \
+                    } \
+                } \
+            } \
         } \
     }
 #ifndef MI355_M3_T
@@ -1311,7 +1466,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                                 uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
                                                 SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
-                                                uint32_t* __restrict__ Mqs) {
+                                                uint32_t* __restrict__ Mqs, uint16_t* __restrict__ advg, ParseCfg pcfg) {
     __shared__ __attribute__((aligned(16))) uint4 s_T[M3_PAIRS / 8];  // T[k] = byte k | byte k+1 << 8, k from the window's start
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -2215,16 +2370,6 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 // deferral needs a strictly longer match (3 .. 258), so a step reads at most 256 entries beyond its position -- no step
 // leaves the tile, the reads are plain LDS reads at 32-bit tile-relative positions (with a 64-entry halo and a fall-back
 // to global memory they were generic loads behind 64-bit selects, and the kernel was bound by its vector instructions).
-constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 260;
-struct TileM {
-    const uint32_t* t;  // the staged tile
-    __device__ uint32_t operator()(uint32_t r) const { return t[r]; }
-};
-// the end of the data the encoder had at a position, relative to a base and clipped to 32 bits
-__device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, uint32_t r) {
-    const uint64_t e = (uint64_t)seg_end(sg, base + r) - base;
-    return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
-}
 __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                              ParseCfg cfg, uint16_t* __restrict__ adv, SegEnds sg, uint32_t blk0) {
     __shared__ __attribute__((aligned(16))) uint32_t sM[ADV_TILE + ADV_HALO], sQ[ADV_TILE + ADV_HALO];
@@ -2270,6 +2415,21 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
     }
 }
 
+// k_adv_tail: the restart steps k_match3 left out -- the last ADV_HALO positions of every epoch that has a successor
+// (their steps look into the next epoch's table).  A workgroup per epoch boundary, the table read from global memory.
+struct GlobM {
+    const uint32_t* g;
+    __device__ uint32_t operator()(uint32_t p) const { return g[p]; }
+};
+__global__ __launch_bounds__(320) void k_adv_tail(uint32_t n, const uint32_t* __restrict__ M, ParseCfg cfg,
+                                                  uint16_t* __restrict__ adv, SegEnds sg) {
+    const uint64_t E1 = ((uint64_t)blockIdx.x + 1) * WINDOW_SIZE;  // the boundary: the first position of the next epoch
+    if (E1 >= n || threadIdx.x >= ADV_HALO) return;
+    const uint32_t p = (uint32_t)E1 - ADV_HALO + threadIdx.x;
+    const GlobM m{M};
+    adv[p] = (uint16_t)parse_step(m, m, p, rel_end(sg, 0, p), cfg).adv;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_seg_exit: for every position of a segment the first path position at or beyond the end of
 // the segment (right-to-left sweep), and the level-0 table over the segment's entry zone.
@@ -2277,15 +2437,8 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
 // One wave per segment, right to left in chunks of 64 positions: a lane whose jump leaves the chunk
 // is resolved at once (from the table of the chunks already done, kept in LDS); jumps that stay
 // inside the chunk are resolved by pointer jumping across lanes (<= 7 rounds).
-__global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
-                                                  uint16_t* __restrict__ X0, uint32_t seg0) {
-    __shared__ uint16_t sJ[4][SEG];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
-    if (k >= K) return;  // whole wave; no workgroup barrier is used below
-    uint16_t* J = sJ[wv];
-    const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
-    const uint32_t len = (uint32_t)(b - a);
+// the sweep of one segment by one wave: J[r] = the exit of position r (relative to the segment's end)
+__device__ __forceinline__ void seg_sweep(const uint16_t* __restrict__ adv, uint64_t a, uint32_t len, uint16_t* J, uint32_t lane) {
     // (all of the segment's jumps are fetched before the sweep: one load per chunk inside it was sixteen memory latencies
     // in a row per wave, and those were the kernel's time)
     uint16_t av[SEG / 64];
@@ -2320,10 +2473,20 @@ __global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const 
         if (valid) J[r] = (uint16_t)val;
         wave_lds_fence();
     }
+}
+__global__ __launch_bounds__(256) void k_seg_exit(uint32_t n, uint32_t K, const uint16_t* __restrict__ adv,
+                                                  uint16_t* __restrict__ X0, uint32_t seg0) {
+    __shared__ uint16_t sJ[4][SEG];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
+    if (k >= K) return;  // whole wave; no workgroup barrier is used below
+    uint16_t* J = sJ[wv];
+    const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    const uint32_t len = (uint32_t)(b - a);
+    seg_sweep(adv, a, len, J, lane);
     uint16_t* x = X0 + k * ZONE;
     for (uint32_t e = lane; e < ZONE; e += 64) x[e] = e < len ? J[e] : (uint16_t)(e - len);
 }
-
 // k_level_up: compose FAN child tables into one parent table.
 // A workgroup per parent unit, a thread per entry of its zone.  The FAN child tables (one contiguous piece of C) are
 // staged in LDS first, every thread fetching its FAN entries at once: an entry's way through the children is a chain of
@@ -2578,21 +2741,28 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __r
     for (uint32_t i = lane; i < c; i += 64) dtok[b + i] = src[i];
 }
 
-// start position of token t (t < T)
+// start position of token t (t < T); the whole wave calls it.  The segment that holds the token -- the last k with
+// base[k] <= t -- by a search that looks at 64 places per round (three rounds for 2^18 segments: a thread's binary
+// search was seventeen memory latencies in a row), the covers of the segment's tokens before t summed across the lanes.
 __device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, const uint32_t* E0,
-                                const uint32_t* tokbuf) {
-    uint32_t lo = 0, hi = K;  // last k with base[k] <= t
+                                const uint32_t* tokbuf, uint32_t lane) {
+    uint32_t lo = 0, hi = K;
     while (hi - lo > 1) {
-        uint32_t mid = lo + (hi - lo) / 2;
-        if (base[mid] <= t)
-            lo = mid;
-        else
-            hi = mid;
+        const uint32_t span1 = hi - lo - 1;
+        const uint32_t p = lo + 1 + (uint32_t)(((uint64_t)span1 * lane) >> 6);  // ascending with the lane, inside (lo, hi)
+        const uint32_t c = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(base[p] <= t));  // (true for a prefix of the lanes)
+        const uint32_t nlo = c ? lo + 1 + (uint32_t)(((uint64_t)span1 * (c - 1)) >> 6) : lo;
+        const uint32_t nhi = c < 64 ? lo + 1 + (uint32_t)(((uint64_t)span1 * c) >> 6) : hi;
+        lo = nlo;
+        hi = nhi;
     }
-    uint32_t pos = E0[lo];
+    const uint32_t m = t - base[lo];
     const uint32_t* tk = tokbuf + (uint64_t)lo * SEG;
-    for (uint32_t i = 0, m = t - base[lo]; i < m; i++) pos += tok_cover(tk[i]);
-    return pos;
+    uint32_t cov = 0;
+    for (uint32_t i = lane; i < m; i += 64) cov += tok_cover(tk[i]);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) cov += __shfl_xor(cov, off, 64);
+    return E0[lo] + cov;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2645,19 +2815,20 @@ __global__ void k_block_count(SegEnds sg, const uint32_t* __restrict__ tend, uin
     sc->nb = acc;
 }
 
-__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode, SegEnds sg,
-                                                     uint32_t sync_final, const uint32_t* __restrict__ tend,
-                                                     const uint32_t* __restrict__ pb, const uint32_t* __restrict__ base,
-                                                     const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
-                                                     const uint32_t* __restrict__ dtok, DevScalars* sc,
-                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13,
-                                                     BlockTab tab) {
-    uint32_t b = blockIdx.x * 64 + threadIdx.x;
+// (a wave per block: token_start is a wave's work)
+__global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode, SegEnds sg,
+                                                      uint32_t sync_final, const uint32_t* __restrict__ tend,
+                                                      const uint32_t* __restrict__ pb, const uint32_t* __restrict__ base,
+                                                      const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
+                                                      const uint32_t* __restrict__ dtok, DevScalars* sc,
+                                                      uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13,
+                                                      BlockTab tab) {
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b > nb_max) return;
     const uint32_t nb = sc->nb;
     if (b > nb) return;
     if (b == nb) {
-        bstart[b] = n;
+        if (lane == 0) bstart[b] = n;
         return;
     }
     uint32_t lo = 0, hi = sg.m;  // segment i with pb[i] <= b < pb[i+1]
@@ -2673,16 +2844,13 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uin
     const uint32_t t0 = tprev + j * MAX_BUFFER_LENGTH;
     const uint32_t left = tend[i] - t0;
     const uint32_t nt = left < MAX_BUFFER_LENGTH ? left : (uint32_t)MAX_BUFFER_LENGTH;
-    tab.t0[b] = t0;
-    tab.nt[b] = nt;
-    tab.sync[b] = (j + 1 == nbi && (i + 1 < sg.m || sync_final)) ? 1u : 0u;
-    bstart[b] = nt ? token_start(t0, K, base, E0, tokbuf) : sg.ends[i];
+    const uint32_t bs = nt ? token_start(t0, K, base, E0, tokbuf, lane) : sg.ends[i];
     uint32_t flag = 0;
     if (nt == MAX_BUFFER_LENGTH) {  // a full block: look at its last token
         uint32_t t1 = t0 + MAX_BUFFER_LENGTH - 1;
         uint32_t tk = dtok[t1];
-        uint32_t tp = token_start(t1, K, base, E0, tokbuf);
-        if (tp < WINDOW_SIZE) {  // the one block that can fill inside the first window (Q1, lz77.rs:628-638)
+        uint32_t tp = token_start(t1, K, base, E0, tokbuf, lane);
+        if (tp < WINDOW_SIZE && lane == 0) {  // the one block that can fill inside the first window (Q1, lz77.rs:628-638)
             sc->b0_full = 1;
             sc->b0_last_tok = tk;
             sc->b0_last_pos = tp;
@@ -2700,7 +2868,13 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t K, uin
             }
         }
     }
-    q13[b] = flag;
+    if (lane == 0) {
+        tab.t0[b] = t0;
+        tab.nt[b] = nt;
+        tab.sync[b] = (j + 1 == nbi && (i + 1 < sg.m || sync_final)) ? 1u : 0u;
+        bstart[b] = bs;
+        q13[b] = flag;
+    }
 }
 
 // the implicit table of the sharded path: blocks of 31744 tokens, no sync markers
