@@ -10,7 +10,7 @@ ctx = da.Context(0); L = da.load(); out = (C.c_ulonglong * 16)()
 ctx.encode(data, da.Compression.Default); L.mi355_debug_sort_stats(out, 1)
 ctx.encode(data, da.Compression.Default); L.mi355_debug_sort_stats(out, 1)
 s = list(out)[:8]
-names = ["hash+hist", "bucket starts", "p1 count", "p1 offsets", "p1 scatter", "p2 count", "p2 offsets", "p2 scatter"]
+names = ["hash+hist", "bucket starts", "p1 count | registers", "p1 offsets | turn", "p1 scatter | scatter", "p2 count", "p2 offsets", "p2 scatter"]  # (two-pass modes | k_sort<2>)
 tot = sum(s); ne = (n + 32767) // 32768
 print("links_ms", ctx.info()["stage_ms"], "cycles per epoch %.0f" % (tot / ne))
 print("  ".join("%s %.3f" % (k, v / tot) for k, v in zip(names, s)))
