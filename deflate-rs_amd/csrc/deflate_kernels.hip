@@ -715,6 +715,9 @@ __global__ __launch_bounds__(1024) void k_lds_order_test(uint32_t rounds, uint32
 // 0.51 ms against 0.45 ms of mode 1 -- the returning adds of ONE wave follow each other at about 100 cycles, so the
 // sixteen turns of an epoch take 50 000 cycles, half of the kernel, with fifteen waves waiting; in mode 1 the sixteen
 // waves' adds are in flight together.
+#ifndef MI355_SORT_P1
+#define MI355_SORT_P1 8
+#endif
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
                                                uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl) {
@@ -746,20 +749,19 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
             const uint32_t nx = *reinterpret_cast<const uint32_t*>(in + E + i + 8);
             const uint32_t d[3] = {w.x, w.y, nx};
             uint32_t hs[8];
+            // (a wave whose 512 positions lie in a run of one byte counts them with one add: 64 lanes on one counter,
+            // eight times over, are served one after the other -- zero-filled input spent half of the kernel here)
+            const bool run1 = w.x == w.y && w.y == nx && w.x == __builtin_amdgcn_alignbyte(w.x, w.x, 1u);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x);
+            const bool wave_run = __builtin_amdgcn_ballot_w64(!run1 || w.x != w0) == 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t v = (k & 3) ? __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t)(k & 3)) : d[k >> 2];
                 hs[k] = hash3(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff);
-                if (MODE == 2) {  // (a wave whose 64 keys share one hash -- a run of one byte -- counts them with one add)
-                    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hs[k]);
-                    if (__builtin_amdgcn_ballot_w64(hs[k] != h0) == 0) {
-                        if ((tid & 63) == 0) atomicAdd(&sBuf[h0 >> 1], (h0 & 1) ? 0x400000u : 64u);
-                        continue;
-                    }
-                }
-                atomicAdd(&sBuf[hs[k] >> 1], (hs[k] & 1) ? 0x10000u : 1u);
+                if (!wave_run) atomicAdd(&sBuf[hs[k] >> 1], (hs[k] & 1) ? 0x10000u : 1u);
             }
             *reinterpret_cast<uint4*>(&sH[i]) = make_uint4(hs[0] | (hs[1] << 16), hs[2] | (hs[3] << 16), hs[4] | (hs[5] << 16), hs[6] | (hs[7] << 16));
+            if (wave_run && (tid & 63) == 0) atomicAdd(&sBuf[hs[0] >> 1], (hs[0] & 1) ? 512u << 16 : 512u);
         }
     } else
     for (uint32_t i0 = 0; i0 < J; i0 += 8 * 1024) {
@@ -810,17 +812,20 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
             run += wds[q] >> 16;
             outw[q] = lo | (hi << 16);
         }
-        uint4* dst = reinterpret_cast<uint4*>(Bg + (size_t)e * BSTRIDE + tid * 32);
-#pragma unroll
-        for (int q = 0; q < 4; q++) dst[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
         if (tid == 1023) Bg[(size_t)e * BSTRIDE + WINDOW_SIZE] = (uint16_t)J;
-        if (MODE == 2) {  // the bucket starts stay: they are the cursors of the ordered pass
-            uint4* cur = reinterpret_cast<uint4*>(sBuf + tid * 16);
+        // (back into their LDS words: they leave as whole lines below -- a thread's own sixteen words were 64-byte pieces
+        // 64 bytes apart: 446 -> 435 us -- and they are the cursors of MODE 2)
+        uint4* cur = reinterpret_cast<uint4*>(sBuf + tid * 16);
 #pragma unroll
-            for (int q = 0; q < 4; q++) cur[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
-        }
+        for (int q = 0; q < 4; q++) cur[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
     }
     __syncthreads();
+    {
+        uint4* dst = reinterpret_cast<uint4*>(Bg + (size_t)e * BSTRIDE);
+        const uint4* src = reinterpret_cast<const uint4*>(sBuf);
+#pragma unroll
+        for (uint32_t k = 0; k < WINDOW_SIZE / 8 / 1024; k++) dst[k * 1024 + tid] = src[k * 1024 + tid];
+    }
     KS_T(1)
     uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
     if (MODE == 2) {
@@ -875,11 +880,12 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         __syncthreads();
         KS_T(4)
     } else if (MODE == 1) {
-        sort_pass_rtn<8>(
-            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
+        constexpr int P1 = MI355_SORT_P1;  // bits of the first digit (the per-wave counter tables hold 256: 7 or 8)
+        sort_pass_rtn<P1>(
+            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & ((1u << P1) - 1u); }, [&](uint32_t i) { return i; },
             [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2);
-        sort_pass_rtn<7>(
-            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
+        sort_pass_rtn<15 - P1>(
+            J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> P1; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
             [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
     } else {
     sort_pass<8>(
