@@ -1960,6 +1960,53 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
         // the first candidate of every lane goes straight to the service
         // (no finding out where they stopped: every lane concerned "left at the first probe of its group")
+#ifdef MI355_M3_NEIGHBOUR
+        // The first candidate of the position at entry j of its bucket is the position at entry j - 1: the lane below, whose
+        // sixteen bytes sit in ITS registers -- one shift of the wave hands them up, where load16 was five 8-byte reads of the
+        // pair table and nine byte selects.  The lanes it cannot serve (lane 0, and the first entry of a bucket, whose first
+        // candidate lies in the previous epoch's) keep the state swg_first gave them -- "left at the first probe" -- and are
+        // settled with the lanes that leave the first block.
+        // (Which lanes wait to be settled needs no book-keeping: they are the ones that neither walk nor are done.)
+        {
+            const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
+            const uint64_t fx = dx & ~sx.in_prev & ~1ull, fy = dy & ~sy.in_prev & ~1ull;
+            if (fx) {
+                uint32_t q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sx.p16[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                swg_service(sx, win, tbase, checks_q, fx, fx, sx.a0, sx.offb + 16u, q);
+            }
+            if (fy) {
+                uint32_t q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy.p16[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                swg_service(sy, win, tbase, checks_q, fy, fy, sy.a0, sy.offb + 16u, q);
+            }
+            M2_CNT(2, 2)
+            M2_CNT(3, __popcll(fx) + __popcll(fy))
+            M2_T(9)
+        }
+        for (;;) {
+            const uint64_t wx = sx.walk, wy = sy.walk;
+            if (wx | wy) {
+                M2_CNT(1, 1)
+                M2_CNT(7, __popcll(wx) + __popcll(wy))
+                uint64_t cx, cy;
+                ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
+                M2_T(12)
+                sx.walk = cx;
+                sy.walk = cy;
+            }
+            const uint64_t dx = ~(sx.walk | sx.done), dy = ~(sy.walk | sy.done);
+            if ((wx | wy | dx | dy) == 0) break;
+            if (dx) settle(sx, dx);
+            if (dy) settle(sy, dy);
+            // (a lane that merely ran out of candidates is not serviced: whoever does not walk now has its result)
+            sx.done |= dx & ~sx.walk;
+            sy.done |= dy & ~sy.walk;
+            M2_T(9)
+        }
+#else
         {
             const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
             if (dx) swg_service(sx, win, tbase, checks_q, dx, dx, sx.a0, sx.offb + 16u);
@@ -1983,6 +2030,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (dy) settle(sy, dy);
             M2_T(9)
         }
+#endif
         swg_result(sx, &pxm, &pxq);
         swg_result(sy, &pym, &pyq);
         pxat = vx ? (Ms ? b * 64 + lane : srx) : ~0u;

@@ -1127,9 +1127,10 @@ MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d, uint32_t width) {
 // probe's address, `ho` = the offset of its entry (the caller picks them from a / t and offb: which step it was
 // is read off the probe bytes; the others left at the end of their group).  Straight-line selects; only a match
 // longer than 16 bytes loops.
+// (qgiven: the candidate's sixteen bytes are handed in -- k_match3's first service takes them from the neighbouring lane)
 template <bool HAS_Q, class W>
 MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
-                          uint32_t asel, uint32_t ho) {
+                          uint32_t asel, uint32_t ho, const uint32_t* qgiven = nullptr) {
     // a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of the window
     // (positions fall along a segment, so the hit's own address tells), is no hit
     // (one comparison per ballot: a ballot of `a && b` makes the compiler turn a lane mask into 0 / 1 values and back)
@@ -1138,7 +1139,14 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
     const uint32_t cpos = ((asel - tbase) >> W::SH) - s.bm1;
     uint32_t q[4];
-    w.load16(cpos, q);
+    if (qgiven) {
+        q[0] = qgiven[0];
+        q[1] = qgiven[1];
+        q[2] = qgiven[2];
+        q[3] = qgiven[3];
+    } else {
+        w.load16(cpos, q);
+    }
     const uint32_t b0 = first_bit_or_ones(q[0] ^ s.p16[0]);
     const uint32_t b1 = first_bit_or_ones(q[1] ^ s.p16[1]) | 32u;
     const uint32_t b2 = first_bit_or_ones(q[2] ^ s.p16[2]) | 64u;

@@ -1,9 +1,11 @@
 #!/bin/bash
-# round-3 final evidence (GPU box, from the repo root)
+# final evidence of a round (GPU box, from the repo root): tools/final_evidence.sh TAG   (default r03_last)
+TAG=${1:-r03_last}
 set -x
-timeout 2400 python -m pytest tests/ -m gpu -x -q > gpurun_out/r03f_gpu_suite.txt 2>&1; tail -3 gpurun_out/r03f_gpu_suite.txt
-python tools/make_profiles.py r03_final > gpurun_out/r03f_make_profiles.log 2>&1; tail -25 gpurun_out/r03f_make_profiles.log
-tools/bench_configs.sh > gpurun_out/r03_final_configs.txt 2>&1; cat gpurun_out/r03_final_configs.txt; cp gpurun_out/bench_configs.jsonl gpurun_out/r03_final_configs.jsonl
-python bench.py > gpurun_out/r03_final_bench_default_run.json 2> gpurun_out/r03f_bench.err; cat gpurun_out/r03_final_bench_default_run.json
-python tools/latency.py > gpurun_out/r03_final_latency.txt 2>&1; cat gpurun_out/r03_final_latency.txt
-python tools/match3_stats.py > gpurun_out/r03_final_k_match3_clock_shares.txt 2>&1; cat gpurun_out/r03_final_k_match3_clock_shares.txt
+timeout 2000 python -m pytest tests/ -m gpu -x -q > gpurun_out/${TAG}_gpu_suite.txt 2>&1; tail -3 gpurun_out/${TAG}_gpu_suite.txt
+timeout 900 python tools/make_profiles.py $TAG > gpurun_out/${TAG}_make_profiles.log 2>&1; tail -25 gpurun_out/${TAG}_make_profiles.log
+timeout 600 tools/bench_configs.sh > gpurun_out/${TAG}_configs.txt 2>&1; cat gpurun_out/${TAG}_configs.txt; cp gpurun_out/bench_configs.jsonl gpurun_out/${TAG}_configs.jsonl
+timeout 600 python bench.py > gpurun_out/${TAG}_bench_default_run.json 2> gpurun_out/${TAG}_bench.err; cat gpurun_out/${TAG}_bench_default_run.json
+timeout 300 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1; cat gpurun_out/${TAG}_latency.txt
+timeout 300 python tools/match3_stats.py > gpurun_out/${TAG}_k_match3_clock_shares.txt 2>&1; cat gpurun_out/${TAG}_k_match3_clock_shares.txt
+timeout 300 python tools/sort_stats.py > gpurun_out/${TAG}_k_sort_clock_shares.txt 2>&1; cat gpurun_out/${TAG}_k_sort_clock_shares.txt
