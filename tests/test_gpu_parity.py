@@ -1055,6 +1055,34 @@ def test_issue_44_on_the_gpu(da, ctx):
         assert zlib.decompress(got) == data
 
 
+# k_sort's three ways to rank a key among the wave's keys of its digit -- ballots (MODE 0), returning LDS atomics in two
+# passes (MODE 1, the default on a device that passes k_lds_order_test) and one pass in position order (MODE 2) -- must give
+# the same sorted arrays, hence the same stream: text, runs of one byte, noise, a partial last epoch, a hash re-warm (Q1).
+# The mode is read when a context is made.
+def test_sort_modes_agree(da):
+    inputs = [datagen.text_like(3_000_000, 0x5157), bytes(700_001), datagen.mixed(2_500_000, 0x77), datagen.rng_bytes(300_003, 5),
+              (b"ab" * 40000 + datagen.text_like(200_000, 9))[:250_017], open(os.path.join(FIX, "pg11.txt"), "rb").read()]
+    old = os.environ.get("MI355_SORT_RTN")
+    try:
+        for mode in ("0", "1", "2", None):
+            if mode is None:
+                os.environ.pop("MI355_SORT_RTN", None)
+            else:
+                os.environ["MI355_SORT_RTN"] = mode
+            c = da.Context(0)
+            try:
+                for data in inputs:
+                    for lv in ("default", "fast", "best"):
+                        agree(da, c, data, *LV[lv])
+            finally:
+                c.close()
+    finally:
+        if old is None:
+            os.environ.pop("MI355_SORT_RTN", None)
+        else:
+            os.environ["MI355_SORT_RTN"] = old
+
+
 # a slice of tools/fuzz_shard.py: random data kind, size, level and 2-8 virtual ranks (also ranges shorter than a
 # block) through the stream-exact sharded encode, against the oracle
 def test_randomized_shards(da):
