@@ -591,6 +591,9 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
     KS_T(stat0 + 2)
 }
 
+#ifndef MI355_SORT_SB
+#define MI355_SORT_SB 4  // batches whose digits are fetched together in the count phase of sort_pass_rtn
+#endif
 // The same pass with the rank of a key taken from the LDS itself: ds_add_rtn on the (wave, digit) counter returns how
 // many of the wave's keys with that digit came before -- batches are instructions in program order, and within one
 // instruction the LDS serves the lanes that hit one address in lane order.  That order is what the hardware does, not
@@ -640,7 +643,7 @@ __device__ __forceinline__ void sort_pass_rtn(uint32_t J, uint32_t* cnt /*16 * 2
             rk[b >> 1] = pk;
         else
             rk[b >> 1] |= pk << 16;
-        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if ((b % MI355_SORT_SB) == MI355_SORT_SB - 1) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     KS_T(stat0)
