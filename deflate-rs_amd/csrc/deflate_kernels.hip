@@ -90,7 +90,10 @@ struct DevScalars {
 };
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
-constexpr uint32_t FAN = 32;    // children per unit in the table tree
+#ifndef MI355_FAN
+#define MI355_FAN 16  // (measured: parse 0.789 / 0.770 / 0.767 / 0.778 / 0.811 ms with 4 / 8 / 16 / 32 / 64 -- more, shorter launches win)
+#endif
+constexpr uint32_t FAN = MI355_FAN;    // children per unit in the table tree
 
 // ---------------------------------------------------------------------------------------------
 // k_links_a / k_links_b: chained_hash_table.rs:118-158 (add_hash_value) for every position, as
@@ -2823,8 +2826,11 @@ __global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __r
         part[blockIdx.x] = t;
     }
 }
+// (tend / pb: a one-shot call has one segment, whose token count and block count are the totals -- written here, and
+// k_seg_tokens / k_block_count are not launched)
 __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ part,
-                                                 uint32_t* __restrict__ base, DevScalars* sc) {
+                                                 uint32_t* __restrict__ base, DevScalars* sc, uint32_t* __restrict__ tend,
+                                                 uint32_t* __restrict__ pb) {
     __shared__ uint32_t wtot[16], red[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // sum of the workgroups before this one
@@ -2851,6 +2857,11 @@ __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __r
         T += all;
         sc->T = T;
         sc->nb = T / MAX_BUFFER_LENGTH + 1;
+        if (tend) {
+            tend[0] = T;
+            pb[0] = 0;
+            pb[1] = T / MAX_BUFFER_LENGTH + 1;
+        }
     }
 }
 // K == 0: no tokens
