@@ -152,13 +152,7 @@ MI355_HD uint32_t first_bit_or_ones(uint32_t x) {
 #endif
 }
 
-MI355_HD uint32_t ctz32(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_ctz(x);
-#else
-    return (uint32_t)__builtin_ctz(x);
-#endif
-}
+MI355_HD uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
 
 // ---- match (matching.rs:87-166 with prev_length = 0) -------------------------------------
 // `W` gives unaligned little-endian 4-byte loads and u16 links in one index space (window
