@@ -2457,40 +2457,101 @@ __global__ __launch_bounds__(M2T, 8) void k_match_coop(const uint8_t* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // k_rle: rle.rs:13-18 get_match_length_rle for every position: R[p] = run of data[p-1]
-// starting at p, capped at 258 and at the end of input.  Each lane owns 16 consecutive
-// positions: one forward scan of at most 258 bytes past its chunk, then a backward recurrence.
+// starting at p, capped at 258 and at the end of input.
+// A workgroup takes a tile of 4096 positions.  "Position i continues the run" (data[i] == data[i-1]) is one bit; a lane
+// works out the sixteen bits of its sixteen positions from five aligned dwords of the staged tile (byte-wise zero test of
+// the words XOR-ed with themselves shifted by one byte) and leaves them in LDS; the run that begins behind its chunk is the
+// number of set bits from there on -- at most seventeen 16-bit words, not 258 byte compares in a row -- and the sixteen
+// results follow from one backward pass over its own bits.  They leave through LDS as whole lines.
+// (Before: bytes staged one by one, the forward scan a loop of up to 258 dependent LDS reads per lane -- on zero fill,
+// BASELINE config 2, every lane ran all of it -- and sixteen 4-byte stores per lane, 64 bytes apart: 3.16 ms for 256 MiB.)
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t RT = 4096;
+constexpr uint32_t RT = 4096;                       // positions of a tile
+constexpr uint32_t RLE_UNITS = RT / 16 + 17;        // 16-position units with bits: the tile and 272 >= MAX_MATCH positions behind it
+constexpr uint32_t RLE_BYTES = 16 + RLE_UNITS * 16; // staged bytes: s[j] = in[E - 16 + j]
 __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ R,
                                              SegEnds sg) {
-    __shared__ __attribute__((aligned(16))) uint8_t s[RT + 258 + 16];  // s[i] = in[E - 1 + i]
+    __shared__ __attribute__((aligned(16))) uint8_t s[RLE_BYTES];
+    __shared__ uint32_t eb[RLE_UNITS + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t so[RT];
     const uint32_t tid = threadIdx.x;
     const uint64_t E = (uint64_t)blockIdx.x * RT;
-    for (uint32_t i = tid; i < RT + 258 + 16; i += 256) {
-        int64_t g = (int64_t)E - 1 + i;
-        s[i] = (g >= 0 && (uint64_t)g < n) ? in[g] : 0;
+    const bool al = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    for (uint32_t k = tid; k < RLE_BYTES / 16; k += 256) {
+        const int64_t g0 = (int64_t)E - 16 + 16 * (int64_t)k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (al && g0 >= 0 && (uint64_t)g0 + 16 <= n) {
+            v = *reinterpret_cast<const uint4*>(in + g0);
+        } else {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 16; b++) {
+                const int64_t g = g0 + b;
+                if (g >= 0 && (uint64_t)g < n) t[b >> 2] |= (uint32_t)in[g] << (8 * (b & 3));
+            }
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        *reinterpret_cast<uint4*>(s + 16 * k) = v;
     }
     __syncthreads();
-    // eq(i) <=> in[E+i] == in[E+i-1], valid for E+i in [1, n)
-    auto eq = [&](uint32_t i) -> bool {
-        uint64_t g = E + i;
-        return g >= 1 && g < n && s[i + 1] == s[i];
+    // the bits of unit u: position i = 16 u + j (tile relative) sits at s[i + 16], the byte before it at s[i + 15]
+    auto unit_bits = [&](uint32_t u) -> uint32_t {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(s + 16 * u + 12);
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+        const uint32_t z[4] = {d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u), d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u),
+                               d3 ^ __builtin_amdgcn_alignbyte(d3, d2, 3u), d4 ^ __builtin_amdgcn_alignbyte(d4, d3, 3u)};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t m = ~(((z[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z[k]) & 0x80808080u;  // bit 7 of every zero byte
+            bits |= ((((m >> 7) * 0x00204081u) >> 21) & 15u) << (4 * k);
+        }
+        // positions 0 and >= n continue nothing (the bytes staged for them are zeros, which may well be equal)
+        const uint64_t g0 = E + 16ull * u;
+        if (g0 == 0) bits &= ~1u;
+        if (g0 + 16 > n) bits &= g0 >= n ? 0u : (1u << (uint32_t)((uint64_t)n - g0)) - 1u;
+        return bits;
     };
-    uint32_t q = tid * 16 + 16;  // first position after my chunk (tile relative)
+    const uint32_t mine = unit_bits(tid);
+    eb[tid] = mine;
+    if (tid < RLE_UNITS - RT / 16) eb[RT / 16 + tid] = unit_bits(RT / 16 + tid);
+    __syncthreads();
+    // the run that begins right behind my sixteen positions
     uint32_t c = 0;
-    while (c < MAX_MATCH && q + c < RT + 258 + 14 && eq(q + c)) c++;
+    for (uint32_t k = tid + 1; k < tid + 18; k++) {
+        const uint32_t x = ~eb[k] & 0xffffu;
+        if (x) {
+            c += (uint32_t)__builtin_ctz(x);
+            break;
+        }
+        c += 16;
+    }
+    c = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
+    uint32_t r16[16];
+#pragma unroll
     for (int i = 15; i >= 0; i--) {
-        uint32_t pr = tid * 16 + i;
-        uint64_t g = E + pr;
-        c = eq(pr) ? c + 1 : 0;
-        if (c > 65535) c = 65535;
-        if (g < n) {
-            uint32_t r = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
-            if (sg.m > 1) {  // a run is cut where the data the encoder had ended (sync flush)
-                uint64_t left = (uint64_t)seg_end(sg, g) - g;
+        c = ((mine >> i) & 1u) ? c + 1 : 0u;
+        uint32_t r = c < MAX_MATCH ? c : (uint32_t)MAX_MATCH;
+        if (sg.m > 1) {  // a run is cut where the data the encoder had ended (sync flush)
+            const uint64_t g = E + tid * 16 + (uint32_t)i;
+            if (g < n) {
+                const uint64_t left = (uint64_t)seg_end(sg, g) - g;
                 if (r > left) r = (uint32_t)left;
             }
-            R[g] = r;
+        }
+        r16[i] = r;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        *reinterpret_cast<uint4*>(so + tid * 16 + 4 * q) = make_uint4(r16[4 * q], r16[4 * q + 1], r16[4 * q + 2], r16[4 * q + 3]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < RT / (4 * 256); k++) {
+        const uint32_t i = (k * 256 + tid) * 4;
+        const uint64_t g = E + i;
+        if (g + 4 <= n) {
+            *reinterpret_cast<uint4*>(R + g) = *reinterpret_cast<const uint4*>(so + i);  // (R is 256-byte aligned, g a multiple of 4)
+        } else {
+            for (uint32_t j = 0; j < 4 && g + j < n; j++) R[g + j] = so[i + j];
         }
     }
 }
