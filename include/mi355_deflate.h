@@ -94,7 +94,10 @@ size_t mi355_deflate_bound_ex(size_t in_len, int wrapper, size_t hdr_len, size_t
  * context per thread (the reference's encoders are likewise single-owner: DeflateState,
  * src/deflate_state.rs:66-97).  Where an entry point accepts ctx == NULL it works on a process-wide
  * default context on device 0 and holds that context's lock for the whole call, so NULL-context calls
- * from several threads are safe (and serialised). */
+ * from several threads are safe (and serialised).
+ * Creating a context runs one short self-test kernel on the device (about 0.1 ms): the hash sort takes its ranks
+ * from returning LDS atomics when -- and only when -- the device serves the lanes that hit one LDS address in lane
+ * order (MI355X does); otherwise it ranks with ballots.  The output is the same either way. */
 typedef struct mi355_deflate_ctx mi355_deflate_ctx;
 int mi355_deflate_ctx_create(int device, mi355_deflate_ctx** out);
 void mi355_deflate_ctx_destroy(mi355_deflate_ctx* ctx);
