@@ -2469,11 +2469,14 @@ __global__ __launch_bounds__(M2T, 8) void k_match_coop(const uint8_t* __restrict
 constexpr uint32_t RT = 4096;                       // positions of a tile
 constexpr uint32_t RLE_UNITS = RT / 16 + 17;        // 16-position units with bits: the tile and 272 >= MAX_MATCH positions behind it
 constexpr uint32_t RLE_BYTES = 16 + RLE_UNITS * 16; // staged bytes: s[j] = in[E - 16 + j]
+// (adv: the restart step of the RLE level -- rle.rs:46-69: a run of three or more is taken whole, else one literal -- needs
+// nothing but the run at the position, so it is written here and k_adv is not launched for this level.)
 __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ R,
-                                             SegEnds sg) {
+                                             uint16_t* __restrict__ adv, SegEnds sg) {
     __shared__ __attribute__((aligned(16))) uint8_t s[RLE_BYTES];
     __shared__ uint32_t eb[RLE_UNITS + 1];
     __shared__ __attribute__((aligned(16))) uint32_t so[RT];
+    __shared__ __attribute__((aligned(16))) uint16_t sa[RT];
     const uint32_t tid = threadIdx.x;
     const uint64_t E = (uint64_t)blockIdx.x * RT;
     const bool al = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
@@ -2543,7 +2546,27 @@ __global__ __launch_bounds__(256) void k_rle(const uint8_t* __restrict__ in, uin
 #pragma unroll
     for (int q = 0; q < 4; q++)
         *reinterpret_cast<uint4*>(so + tid * 16 + 4 * q) = make_uint4(r16[4 * q], r16[4 * q + 1], r16[4 * q + 2], r16[4 * q + 3]);
+    {
+        uint32_t a16[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) a16[i] = r16[i] >= MIN_MATCH ? r16[i] : 1u;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            *reinterpret_cast<uint4*>(sa + tid * 16 + 8 * q) =
+                make_uint4(a16[8 * q] | (a16[8 * q + 1] << 16), a16[8 * q + 2] | (a16[8 * q + 3] << 16),
+                           a16[8 * q + 4] | (a16[8 * q + 5] << 16), a16[8 * q + 6] | (a16[8 * q + 7] << 16));
+    }
     __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < RT / (8 * 256); k++) {
+        const uint32_t i = (k * 256 + tid) * 8;
+        const uint64_t g = E + i;
+        if (g + 8 <= n) {
+            *reinterpret_cast<uint4*>(adv + g) = *reinterpret_cast<const uint4*>(sa + i);  // (adv is 256-byte aligned, g a multiple of 8)
+        } else {
+            for (uint32_t j = 0; j < 8 && g + j < n; j++) adv[g + j] = sa[i + j];
+        }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < RT / (4 * 256); k++) {
         const uint32_t i = (k * 256 + tid) * 4;
