@@ -30,9 +30,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+ENWIK8_PATHS = [os.environ.get("MI355_ENWIK8", ""), os.path.join(ROOT, "data", "enwik8"), "/data/enwik8"]
+INPUT_NOTE = {}
+
+
 def make_input(workload, size, rank):
     import datagen
     if workload == "enwik8":
+        # the real enwik8 when the box has it (there is no network to fetch it: data/enwik8 or
+        # $MI355_ENWIK8), else enwik8-like synthetic text of the same size; the bench line says which
+        for p in ENWIK8_PATHS:
+            if p and os.path.isfile(p) and os.path.getsize(p) >= size * (rank + 1):
+                with open(p, "rb") as f:
+                    f.seek(size * rank)
+                    INPUT_NOTE["enwik8"] = "the real enwik8 (%s)" % p
+                    return f.read(size)
+        INPUT_NOTE["enwik8"] = "enwik8-like synthetic text (tests/datagen.py text_like; no data/enwik8 on this box)"
         return datagen.text_like(size, 0x656E77696B38 ^ rank)
     if workload == "zeros":
         return bytes(size)
@@ -257,12 +270,10 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * size * args.steps / elapsed / 1e6
         mm = sum(match_ms) / len(match_ms)
-        try:
-            mpath = int(da.load().mi355_debug_match_path())
-        except AttributeError:
-            mpath = int(os.environ.get("MI355_MATCH_PATH", "2"))
-        sorted_walk = lvl in ("default", "best") and mpath != 1
-        dominant = "k_rle" if lvl == "rle" else ({4: "k_match3", 5: "k_match4", 6: "k_match5"}.get(mpath, "k_match2") if sorted_walk else "k_match")
+        # every level with a hash budget runs k_sort + k_match3 (Fast included); rle() runs k_rle; huffman_only() has no
+        # match stage (the table is a fill)
+        sorted_walk = lvl in ("default", "best", "fast")
+        dominant = "k_rle" if lvl == "rle" else ("k_match3" if sorted_walk else "fill")
         # 1 B read + r B written per input byte; one launch of the dominant kernel = one rank's bytes
         algo_bytes = size + (total_out // world)
         achieved = algo_bytes / (mm * 1e-3) / 1e9 if mm > 0 else 0.0
@@ -311,11 +322,12 @@ def main():
             "metric": "MB/s raw input encoded (%s) + compressed size vs ref" % level_name,
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d bytes per GPU, %s, %s" % (
-                args.workload, size, level_name,
+            "dtype": "u8", "data": "real" if "real" in INPUT_NOTE.get(args.workload, "") else "synthetic",
+            "config": {"workload": "%s%s: %d bytes per GPU, %s, %s" % (
+                args.workload, " = " + INPUT_NOTE[args.workload] if args.workload in INPUT_NOTE else "", size, level_name,
                 "stream-exact (P1)" if world == 1 else (
-                    "one %d-byte input sharded over %d GPUs, stream-exact (P1), RCCL stitch" % (total, world)
+                    "one %d-byte input sharded over %d GPUs, stream-exact (P1), stitch over %s" % (
+                        total, world, "RCCL" if backend == "nccl" else backend + " (dry run: the ranks may share a GPU)")
                     if shard_mode == "p1" else "chunk-exact (P2) stitch across GPUs")),
                 "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % world},
             "out_bytes": total_out, "ratio": round(total_out / (world * size), 5),

@@ -3,19 +3,21 @@
 // One kernel per stage of stages.h; every kernel names the reference code it stands in for.
 // Layout of the per-encode workspace in HBM (n = input bytes, K = ceil(n / SEG) segments,
 // nb <= n / 31744 + 1 blocks):
-//   S      u16[n]      per 32 KiB epoch: positions sorted by (filing hash, position)  2 B/byte   (k_sort -> k_match2)
+//   S      u16[n]      per 32 KiB epoch: positions sorted by (filing hash, position)  2 B/byte   (k_sort -> k_match3; stored as 2 x position)
 //   B      u16[32776 per epoch]  start of every hash bucket in the epoch's S       2 B/byte
 //   link   u16[n]      distance to the previous position with the same hash (k_links -> k_match: the first two
-//                      epochs of a re-warmed stream, streams with late-filed positions, budgets under 16)
+//                      epochs of a re-warmed stream, streams with late-filed positions)
 //   M, Mq  u32[n]      longest_match(prev_length = 0) at full / quarter budget   4 (+4) B/byte
 //   adv    u16[n]      restart step length from every position                   2 B/byte
 //   J      u16[n]      scratch of the per-segment exit sweep                     2 B/byte
 //   X[l]   u16[K_l*ZONE]  exit tables per level (an exit lies less than MAX_JUMP beyond its unit), E[l] u32[K_l] entry positions
 //   tokbuf u32[K*SEG]  tokens per segment, dtok u32[T] tokens in stream order    4 + 4 B/byte
 //   per block: ll_freq u32[4][288], d_freq u32[4][32] (a histogram per quarter of the block), BlockHeader, BlockPlan, bstart
-// All integer work; the bound is vector-ALU issue / LDS in k_match2 and latency or HBM elsewhere.
+// All integer work; the bound is vector-ALU issue / LDS in k_match3 and latency or HBM elsewhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #ifdef MI355_MATCH_STATS
 // instrumented build (tools/variants.sh): per-lane counters of match_walk_park, summed over the launch
@@ -87,6 +89,13 @@ struct DevScalars {
     uint32_t adler;
     uint32_t crc;          // CRC-32 of the input (gzip trailer), XOR-accumulated by k_crc_fold
     uint64_t adler_a, adler_b;  // sums of the chunk contributions (k_adler_part)
+};
+
+// ... and what outlives the clearing of the scalars at the start of an encode
+struct DevState {
+    DevScalars sc;
+    uint32_t sort_bad;  // k_match3 met a bucket whose entries do not ascend: k_sort's ranks from LDS atomics cannot be trusted
+    uint32_t pad[3];
 };
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(MTHREADS) void k_match(const uint8_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sort + k_match2: the same longest_match table over hash-SORTED positions (stages.h SortedLane).
+// k_sort + k_match3: the same longest_match table over hash-SORTED positions (stages.h SwG).
 //
 // k_sort (one workgroup per 32 KiB epoch) stands in for chained_hash_table.rs:118-158 as a whole: it
 // files every position of the epoch under its 15-bit hash, in position order -- S_e = the epoch's
@@ -712,15 +721,9 @@ __global__ __launch_bounds__(1024) void k_lds_order_test(uint32_t rounds, uint32
     if (wrong) atomicAdd(bad, wrong);
 }
 
-// MODE 0: ranks from ballots (sort_pass), 1: from returning atomics, two passes (sort_pass_rtn), 2: ONE pass in position
-// order -- the bucket starts, which are wanted anyway, become cursors, and a returning add on a key's cursor IS its place
-// in the sorted array as long as the adds happen in position order: within an instruction the LDS sees to that (lane
-// order, k_lds_order_test), within a wave program order does, and the sixteen waves of the epoch take turns.  Only
-// the adds themselves are inside a turn (32 instructions; addresses and increments wait in registers): counting,
-// offsets and scatter of two radix passes (two thirds of the kernel) shrink to one scatter.  MEASURED, NOT THE DEFAULT:
-// 0.51 ms against 0.45 ms of mode 1 -- the returning adds of ONE wave follow each other at about 100 cycles, so the
-// sixteen turns of an epoch take 50 000 cycles, half of the kernel, with fifteen waves waiting; in mode 1 the sixteen
-// waves' adds are in flight together.
+// MODE 0: ranks from ballots (sort_pass), 1: from returning atomics (sort_pass_rtn).  (A third form -- ONE pass in
+// position order with the bucket starts as cursors, the sixteen waves taking turns -- was measured at 0.51 ms against
+// 0.45 ms and is in the history of this file: DESIGN.md section 5.)
 #ifndef MI355_SORT_P1
 #define MI355_SORT_P1 8
 #endif
@@ -729,11 +732,11 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
                                                uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl) {
     __shared__ __attribute__((aligned(16))) uint16_t sH[WINDOW_SIZE];  // hashes; the sorted array at the end
     __shared__ __attribute__((aligned(16))) uint32_t sBuf[WINDOW_SIZE / 2];  // histogram (u16 pairs), then pass-1 output (u16) / cursors
-    __shared__ uint32_t sCnt[MODE == 2 ? 1 : 16 * 256];
+    __shared__ uint32_t sCnt[16 * 256];
     __shared__ uint32_t sRed[16];
-    __shared__ uint32_t s_turn;
+    __shared__ uint32_t s_runs;  // pieces of 512 positions that lie in a run of one byte
     const uint32_t tid = threadIdx.x;
-    if (MODE == 2 && tid == 0) s_turn = 0;
+    if (tid == 0) s_runs = 0;
     const uint32_t e = e0 + blockIdx.x;
     const uint64_t E = (uint64_t)e * WINDOW_SIZE;
     const uint32_t J = epoch_active(n, E);
@@ -767,7 +770,10 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
                 if (!wave_run) atomicAdd(&sBuf[hs[k] >> 1], (hs[k] & 1) ? 0x10000u : 1u);
             }
             *reinterpret_cast<uint4*>(&sH[i]) = make_uint4(hs[0] | (hs[1] << 16), hs[2] | (hs[3] << 16), hs[4] | (hs[5] << 16), hs[6] | (hs[7] << 16));
-            if (wave_run && (tid & 63) == 0) atomicAdd(&sBuf[hs[0] >> 1], (hs[0] & 1) ? 512u << 16 : 512u);
+            if (wave_run && (tid & 63) == 0) {
+                atomicAdd(&sBuf[hs[0] >> 1], (hs[0] & 1) ? 512u << 16 : 512u);
+                atomicAdd(&s_runs, 1u);
+            }
         }
     } else
     for (uint32_t i0 = 0; i0 < J; i0 += 8 * 1024) {
@@ -818,9 +824,13 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
             run += wds[q] >> 16;
             outw[q] = lo | (hi << 16);
         }
-        if (tid == 1023) Bg[(size_t)e * BSTRIDE + WINDOW_SIZE] = (uint16_t)J;
+        if (tid == 1023) {
+            Bg[(size_t)e * BSTRIDE + WINDOW_SIZE] = (uint16_t)J;
+            // (k_match3 walks such an epoch with the one-sided long compare: more than half of it in runs of one byte)
+            Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 1] = s_runs > WINDOW_SIZE / 512 / 2 ? 1 : 0;
+        }
         // (back into their LDS words: they leave as whole lines below -- a thread's own sixteen words were 64-byte pieces
-        // 64 bytes apart: 446 -> 435 us -- and they are the cursors of MODE 2)
+        // 64 bytes apart: 446 -> 435 us)
         uint4* cur = reinterpret_cast<uint4*>(sBuf + tid * 16);
 #pragma unroll
         for (int q = 0; q < 4; q++) cur[q] = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
@@ -834,58 +844,7 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     }
     KS_T(1)
     uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
-    if (MODE == 2) {
-        typedef __attribute__((address_space(3))) uint32_t* lds_u32;
-        constexpr int NBAT = SORT_CHUNK / 64;  // batches per wave
-        const uint32_t lane = tid & 63, wv = tid >> 6;
-        const uint32_t cb = wv * SORT_CHUNK;
-        const uint32_t cur0 = (uint32_t)(uintptr_t)(lds_u32)sBuf;
-        uint32_t ad[NBAT];   // LDS address of the key's cursor word
-        uint32_t inc[NBAT];  // what the lane adds to it (0: nothing); afterwards what came back
-        uint32_t par = 0;    // bit b: the key's hash is odd -- its cursor is the high half of the word
-        uint32_t unim = 0;   // bit b: the batch's keys share one hash: lane 0 adds for all, a lane's place follows from its number
-#pragma unroll
-        for (int b = 0; b < NBAT; b++) {
-            const uint32_t i = cb + 64 * b + lane;
-            const bool valid = i < J;
-            const uint32_t h = valid ? (uint32_t)sH[i] : 0u;
-            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-            const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
-            const bool uni = __builtin_amdgcn_ballot_w64(valid && h != h0) == 0;  // (lane 0 is valid whenever a lane is)
-            const uint32_t sh = (h & 1u) << 4;
-            ad[b] = cur0 + ((h >> 1) << 2);
-            inc[b] = uni ? (lane == 0 ? (uint32_t)__popcll(vm) << sh : 0u) : (valid ? 1u << sh : 0u);
-            par |= (h & 1u) << b;
-            unim |= uni ? 1u << b : 0u;
-            asm volatile("" : "+v"(ad[b]), "+v"(inc[b]));  // (in registers NOW: the compiler would work them out again inside the turn)
-        }
-        unim = (uint32_t)__builtin_amdgcn_readfirstlane((int)unim);
-        __syncthreads();  // every wave holds its hashes: their array is free for the sorted one
-        KS_T(2)
-        while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != wv) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int b = 0; b < NBAT; b++)
-            if (inc[b]) inc[b] = __hip_atomic_fetch_add((lds_u32)(uintptr_t)ad[b], inc[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the adds have happened
-        if (lane == 0) __hip_atomic_store(&s_turn, wv + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        KS_T(3)
-#pragma unroll
-        for (int b = 0; b < NBAT; b++) {
-            const uint32_t i = cb + 64 * b + lane;
-            const bool valid = i < J;
-            uint32_t r = inc[b], odd = (par >> b) & 1u, add = 0;
-            if ((unim >> b) & 1u) {
-                r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-                odd = (uint32_t)__builtin_amdgcn_readfirstlane((int)odd);
-                const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
-                add = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-            }
-            const uint32_t at = ((odd ? r >> 16 : r) & 0xffffu) + add;
-            if (valid) sH[at] = (uint16_t)i;
-        }
-        __syncthreads();
-        KS_T(4)
-    } else if (MODE == 1) {
+    if (MODE == 1) {
         constexpr int P1 = MI355_SORT_P1;  // bits of the first digit (the per-wave counter tables hold 256: 7 or 8)
         sort_pass_rtn<P1>(
             J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & ((1u << P1) - 1u); }, [&](uint32_t i) { return i; },
@@ -903,6 +862,24 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> 8; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
         [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
     }
+#ifdef MI355_DEBUG_HOOKS
+    // test build: what a device would do whose LDS served the lanes of an atomic out of order -- two neighbours of one
+    // bucket change places (dbl bit 1; mi355_debug_break_sort)
+    if ((dbl & 2u) && tid == 0) {
+        for (uint32_t i = 1; i < J; i++) {
+            const uint32_t a = sH[i - 1], b = sH[i];
+            const uint8_t* pa = in + E + a;
+            const uint8_t* pb = in + E + b;
+            if (E + b + 2 < n && hash3(pa[0], pa[1], pa[2]) == hash3(pb[0], pb[1], pb[2])) {
+                sH[i - 1] = (uint16_t)b;
+                sH[i] = (uint16_t)a;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    dbl &= 1u;
+#endif
     uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
     const uint4* fin = reinterpret_cast<const uint4*>(sH);
     // dbl = 1: entries as 2 * position (k_match3 adds them to a pair-table address); positions are below 32768,
@@ -911,139 +888,6 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         const uint4 v = fin[k];
         out[k] = make_uint4(v.x << dbl, v.y << dbl, v.z << dbl, v.w << dbl);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_match2: matching.rs:87-166 for the positions of one epoch, taken 64 at a time in the order of S_e
-// (so the lanes of a wave are neighbours in a hash bucket: their candidate lists are the same array
-// shifted by one, their reads of it coalesce, and their chains have nearly the same length).  LDS holds
-// the bytes of the previous and the own epoch (+ 258 lookahead); the sorted arrays are read from
-// global memory / L2 (a wave-step touches one or two lines of them).  Lanes walk in lockstep under the
-// execution mask; every M2_R steps the lanes that left the walk are serviced (stages.h sw_service).
-// ---------------------------------------------------------------------------------------------
-#ifndef MI355_M2_THREADS
-#define MI355_M2_THREADS 1024
-#endif
-#ifndef MI355_M2_R
-#define MI355_M2_R 12
-#endif
-constexpr uint32_t M2T = MI355_M2_THREADS;
-constexpr uint32_t M2_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
-
-struct SortWin {
-    const uint16_t* sb;   // global: index 0 = entry 0 of the previous epoch's sorted array
-    // byte coordinates are LDS addresses
-    // gfx950 reads LDS at any byte address (ds_read_u16 / _b32 / _b128 return the right bytes,
-    // tools/probes/lds_unaligned.hip), but misaligned reads are slow.  Measured on the bench input: these
-    // two loads as single unaligned reads, match stage 4.18 -> 5.54 ms; the step's probe as one ds_read_u16
-    // instead of two ds_read_u8 (MI355_LDS_UNALIGNED_STEP), 4.18 -> 8.19 ms.  Hence aligned dwords and
-    // v_alignbyte here, and byte reads in the step.
-#ifdef MI355_LDS_UNALIGNED_LOADS
-    __device__ uint32_t load32(uint32_t i) const {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        return *(__attribute__((address_space(3))) const u32u*)i;
-    }
-    __device__ void load128(uint32_t i, uint32_t* q) const {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        const __attribute__((address_space(3))) u32u* p = (const __attribute__((address_space(3))) u32u*)i;
-        q[0] = p[0];
-        q[1] = p[1];
-        q[2] = p[2];
-        q[3] = p[3];
-    }
-#else
-    __device__ uint32_t load32(uint32_t i) const {
-        typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
-        lds_u32 w = (lds_u32)(i & ~3u);
-        uint32_t lo = w[0], hi = w[1];
-        return __builtin_amdgcn_alignbyte(hi, lo, i);
-    }
-    // 16 bytes at any byte offset: five aligned dwords, four v_alignbyte
-    __device__ void load128(uint32_t i, uint32_t* q) const {
-        typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
-        lds_u32 w = (lds_u32)(i & ~3u);
-        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-        q[0] = __builtin_amdgcn_alignbyte(d1, d0, i);
-        q[1] = __builtin_amdgcn_alignbyte(d2, d1, i);
-        q[2] = __builtin_amdgcn_alignbyte(d3, d2, i);
-        q[3] = __builtin_amdgcn_alignbyte(d4, d3, i);
-    }
-#endif
-    __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }  // (i may be -1: read ahead)
-};
-
-// M2_R chain steps (stages.h swl_steps_ref) for the lanes of `walk`, as one block of hand-scheduled code:
-// the lanes run under the execution mask, which only shrinks inside the block -- a lane whose candidate
-// is out of reach, passes the probe, or was the last of its run simply drops out and keeps its registers
-// for the service.  Per step: the candidate's two probe bytes from LDS and three compares that write EXEC.
-// The sorted array's entries come four at a time (one 8-byte load per lane and group of four steps, the
-// next group in flight meanwhile: a two-byte load per step kept the address unit busier than the vector
-// ALU); a step takes its entry as a 16-bit operand select (SDWA) of the group's registers, which are
-// fixed (v56..v59) because an operand cannot name the halves of a pair.  offb = 2 * off + 8 is the byte
-// offset of the current entry from sb8 = array base - 8 bytes (the offset register of a global load is
-// unsigned).  Returns the lanes that are still walking.
-#ifdef MI355_LDS_UNALIGNED_STEP
-#define M2_PROBE                                      \
-    "ds_read_u16 %[t0], %[a]\n\t"                     \
-    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"          \
-    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"        \
-    "s_waitcnt lgkmcnt(0)\n\t"
-#else
-#define M2_PROBE                                      \
-    "ds_read_u8 %[t0], %[a]\n\t"                      \
-    "ds_read_u8 %[t1], %[a] offset:1\n\t"             \
-    "v_add_u32_e32 %[offb], -2, %[offb]\n\t"          \
-    "v_cmpx_ge_u32_e32 vcc, %[a], %[lowa]\n\t"        \
-    "s_waitcnt lgkmcnt(0)\n\t"                        \
-    "v_lshl_or_b32 %[t0], %[t1], 8, %[t0]\n\t"
-#endif
-#define M2_STEP(REG, HALF)                                                                     \
-    "v_add_u32_sdwa %[a], " REG ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t" \
-    M2_PROBE                                                                                   \
-    "v_cmpx_ne_u32_e32 vcc, %[t0], %[probe]\n\t"                                               \
-    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"                                              \
-    "s_cbranch_execz .Lm2_end%=\n\t"
-// a group: entries off, off-1 in the high register (high half first), off-2, off-3 in the low one
-#define M2_GROUP(LO, HI) M2_STEP(HI, "WORD_1") M2_STEP(HI, "WORD_0") M2_STEP(LO, "WORD_1") M2_STEP(LO, "WORD_0")
-static_assert(MI355_M2_R % 4 == 0 && MI355_M2_R >= 8 && MI355_M2_R <= 16, "whole groups of four steps");
-
-__device__ __forceinline__ uint64_t m2_steps(uint32_t& offb, uint32_t& a, uint32_t& rv, uint32_t bb, uint32_t lowa,
-                                             uint32_t probe, uint32_t endb, const uint16_t* sb8, uint64_t walk) {
-    uint32_t t1;
-    uint64_t save, still;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[walk]\n\t"
-        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"   // entries off-3 .. off
-        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"  // entries off-7 .. off-4
-        "s_waitcnt vmcnt(1)\n\t"
-        M2_GROUP("v56", "v57")
-#if MI355_M2_R >= 12
-        "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t"  // (offb has moved on by four entries)
-#endif
-        "s_waitcnt vmcnt(1)\n\t"
-        M2_GROUP("v58", "v59")
-#if MI355_M2_R >= 12
-#if MI355_M2_R >= 16
-        "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-#else
-        "s_waitcnt vmcnt(0)\n\t"
-#endif
-        M2_GROUP("v56", "v57")
-#endif
-#if MI355_M2_R >= 16
-        "s_waitcnt vmcnt(0)\n\t"
-        M2_GROUP("v58", "v59")
-#endif
-        ".Lm2_end%=:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 %[still], exec\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        : [offb] "+v"(offb), [a] "+v"(a), [t0] "+v"(rv), [t1] "=&v"(t1), [save] "=&s"(save), [still] "=&s"(still)
-        : [bb] "v"(bb), [lowa] "v"(lowa), [probe] "v"(probe), [endb] "v"(endb), [sb] "s"(sb8), [walk] "s"(walk)
-        : "vcc", "memory", "v56", "v57", "v58", "v59");
-    return still;
 }
 
 #ifdef MI355_MATCH_STATS
@@ -1061,155 +905,16 @@ __device__ __forceinline__ uint64_t m2_steps(uint32_t& offb, uint32_t& a, uint32
 #define M2_T(i)
 #endif
 
-template <bool HAS_Q>
-__global__ __launch_bounds__(M2T, 8) void k_match2(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
-                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
-                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q,
-                                                int in_aligned16, SegEnds sg, HashOverride ov, uint32_t e0,
-                                                uint32_t split) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_by[M2_BYTES];
-    __shared__ uint32_t s_next;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
-    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
-    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
-    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
-    if (in_aligned16) {
-        for (uint32_t w = tid; w < wbytes / 16; w += M2T) {
-            const uint64_t g = wbase + 16ull * w;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (g + 16 <= n) {
-                v = *reinterpret_cast<const uint4*>(in + g);
-            } else {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int b = 0; b < 16; b++)
-                    if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            reinterpret_cast<uint4*>(s_by)[w] = v;
-        }
-    } else {
-        uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_by);
-        for (uint32_t w = tid; w < wbytes / 4; w += M2T) {
-            const uint64_t g = wbase + 4ull * w;
-            uint32_t v = 0;
-            for (int b = 0; b < 4; b++)
-                if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
-            sb32[w] = v;
-        }
-    }
-    const uint32_t J = epoch_active(n, E);
-    const uint32_t nbat = (J + 63) / 64;
-    const uint32_t b_lo = (uint32_t)((uint64_t)nbat * part / split), b_hi = (uint32_t)((uint64_t)nbat * (part + 1) / split);
-    if (tid == 0) s_next = b_lo;
-    if (part == 0 && tid < 2) {  // the positions without a hash byte (the last two of the input) are never searched
-        const uint64_t p = E + J + tid;
-        if (p < n && p < E + WINDOW_SIZE) {
-            M[p] = 0;
-            if (HAS_Q) Mq[p] = 0;
-        }
-    }
-    __syncthreads();
-    // byte coordinates = LDS addresses: org = the window's first byte, bias = the own epoch's first byte
-    const uint32_t org = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_by;
-    const uint32_t bias = org + (uint32_t)(E - wbase);
-    // (the array pointer may lie before the array for epoch 0; only indices >= 32768 - 2 are read then, and
-    // the array has a pad in front)
-    const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;
-    SortWin win{sbase};
-    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
-    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
-    const uint16_t* Bprev = Bown - BSTRIDE;
-    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
-#ifdef MI355_MATCH_STATS
-    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    M2_T0
-    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= b_hi) break;
-        const uint32_t j = b * 64 + lane;
-        const bool valid = j < J;
-        SwLean<HAS_Q> st;
-        uint32_t srel = 0;
-        bool search = false;
-        if (valid) {
-            srel = own[j];
-            const uint32_t prel = bias + srel;
-            const uint32_t v = win.load32(prel);
-            const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
-            const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
-            const uint32_t ob = Bown[h];
-            uint32_t pb0 = 0, pb1 = 0;
-            if (e) {
-                pb0 = Bprev[h];
-                pb1 = Bprev[h + 1];
-            }
-            search = swl_setup(st, win, j, ob, pb0, pb1, prel, org + lim(prel - org), org, bias, checks, checks_q);
-        } else {
-            (void)swl_setup(st, win, 0u, 0u, 0u, 0u, bias, bias, org, bias, checks, checks_q);
-        }
-        const uint64_t start = __builtin_amdgcn_ballot_w64(search);
-        st.done = ~start;
-        swl_start(st, org, start);
-        M2_CNT(0, 1)
-        M2_T(8)
-#ifndef MI355_M2_STORE_AT_ONCE
-        // The results of the batch before go out here, behind this batch's set-up loads: stores count in
-        // vmcnt like loads, and 64 scattered ones issued at the end of a batch made the next batch's first
-        // load wait for them.
-        if (pend_at != ~0u) {
-            M[E + pend_at] = pend_m;
-            if (HAS_Q) Mq[E + pend_at] = pend_mq;
-        }
-#endif
-        for (;;) {
-            const uint64_t walk = st.walk;
-            if (walk == 0) break;
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(walk))
-            const uint64_t still = m2_steps(st.offb, st.a, st.rv, st.bb, st.lowa, st.probe, st.endb, sbase - 4, walk);
-            M2_T(12)
-            st.walk = still;
-            swl_service(st, win, org, walk & ~still, (uint64_t)0);
-            M2_T(9)
-        }
-#ifdef MI355_M2_STORE_AT_ONCE
-        if (valid) {
-            uint32_t m, mq;
-            swl_result(st, &m, &mq);
-            M[E + srel] = m;
-            if (HAS_Q) Mq[E + srel] = mq;
-        }
-#else
-        swl_result(st, &pend_m, &pend_mq);
-        pend_at = valid ? srel : ~0u;
-#endif
-        M2_T(13)
-    }
-#ifndef MI355_M2_STORE_AT_ONCE
-    if (pend_at != ~0u) {
-        M[E + pend_at] = pend_m;
-        if (HAS_Q) Mq[E + pend_at] = pend_mq;
-    }
-#endif
-#ifdef MI355_MATCH_STATS
-    if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_match3: matching.rs:87-166 for the positions of one epoch, in the order of S_e like k_match2, with the
-// window held in LDS as a table of byte PAIRS (stages.h SwG): the probe of a candidate is ONE aligned
-// two-byte read -- k_match2's two one-byte reads cost two trips through the LDS banks per visit, and the LDS
-// array was 76 % busy, half of it bank conflicts -- and the step block asks about four candidates at a time:
-// four address adds, four reads in flight, four compares that shrink EXEC, and the bookkeeping (entry offset,
+// k_match3: matching.rs:87-166 for the positions of one epoch, taken 64 at a time in the order of S_e (so the
+// lanes of a wave are neighbours in a hash bucket: their candidate lists are the same array shifted by one and
+// their reads of it coalesce), with the window held in LDS as a table of byte PAIRS (stages.h SwG): the probe of
+// a candidate is ONE aligned two-byte read, and the step block asks about eight candidates at a time: eight
+// address adds, eight reads in flight, eight compares that shrink EXEC, and the bookkeeping (entry offset,
 // window, entries left) once per group instead of once per step.  The table is 2 B per position of the
-// previous and the own epoch: 131.6 KB, one workgroup of 16 waves per CU (k_match2: two of them at 64 KB).
+// previous and the own epoch: 131.6 KB, one workgroup of 16 waves per CU.  (The byte-image form of round 2,
+// k_match2, and the forms that were measured and lost -- k_match4, k_match5, k_match_coop, refill -- are in
+// the history of this file and in DESIGN.md section 5.)
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t M3T = 1024;
 constexpr uint32_t M3_PAIRS = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16: pairs in the table (= bytes staged)
@@ -1254,102 +959,7 @@ struct PairWin {
     __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
 };
 
-// A block of chain steps (stages.h swg_group_ref) for the lanes of `walk`: two groups of eight steps (SHAPE 8) or
-// three groups of four (SHAPE 4).  Per group: the entries of one 16- / 8-byte load become probe addresses (16-bit
-// operand selects of the load's registers, fixed v56..v63), the table reads (RD: ds_read_u16 of the pair table,
-// ds_read_u8 of the pair-hash table) are issued back to back, and each answer shrinks EXEC when it equals the
-// lane's probe key; then the window test on the last address and "entries left".  A lane that leaves keeps a / t
-// of its last group, offb already a group further: the service finds out where it stopped.
-#define MS_ADD(A, REG, HALF) "v_add_u32_sdwa %[" A "], " REG ", %[bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t"
-#define MS_CMP(N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" T "], %[probe]\n\t"
-#define MS_TAIL(ALAST)                                 \
-    "v_cmpx_ge_u32_e32 vcc, %[" ALAST "], %[lowa]\n\t" \
-    "v_cmpx_ge_i32_e32 vcc, %[offb], %[endb]\n\t"      \
-    "s_cbranch_execz .Lms_end%=\n\t"
-#define MS_G4(RD, LO, HI, MID)                                                                             \
-    MS_ADD("a0", HI, "WORD_1") MS_ADD("a1", HI, "WORD_0") MS_ADD("a2", LO, "WORD_1") MS_ADD("a3", LO, "WORD_0") \
-    RD " %[t0], %[a0]\n\t" RD " %[t1], %[a1]\n\t" RD " %[t2], %[a2]\n\t" RD " %[t3], %[a3]\n\t"             \
-    "v_add_u32_e32 %[offb], -8, %[offb]\n\t" MID                                                           \
-    MS_CMP("3", "t0") MS_CMP("2", "t1") MS_CMP("1", "t2") MS_CMP("0", "t3") MS_TAIL("a3")
-#define MS_G8(RD, R0, R1, R2, R3)                                                                          \
-    MS_ADD("a0", R3, "WORD_1") MS_ADD("a1", R3, "WORD_0") MS_ADD("a2", R2, "WORD_1") MS_ADD("a3", R2, "WORD_0") \
-    MS_ADD("a4", R1, "WORD_1") MS_ADD("a5", R1, "WORD_0") MS_ADD("a6", R0, "WORD_1") MS_ADD("a7", R0, "WORD_0") \
-    RD " %[t0], %[a0]\n\t" RD " %[t1], %[a1]\n\t" RD " %[t2], %[a2]\n\t" RD " %[t3], %[a3]\n\t"             \
-    RD " %[t4], %[a4]\n\t" RD " %[t5], %[a5]\n\t" RD " %[t6], %[a6]\n\t" RD " %[t7], %[a7]\n\t"             \
-    "v_add_u32_e32 %[offb], -16, %[offb]\n\t"                                                              \
-    MS_CMP("7", "t0") MS_CMP("6", "t1") MS_CMP("5", "t2") MS_CMP("4", "t3")                                \
-    MS_CMP("3", "t4") MS_CMP("2", "t5") MS_CMP("1", "t6") MS_CMP("0", "t7") MS_TAIL("a7")
-// two groups of eight: entries off-7 .. off and off-15 .. off-8, both loaded at the start
-#define MS_LOADS8                                                        \
-    "global_load_dwordx4 v[56:59], %[offb], %[sb] offset:-14\n\t"        \
-    "global_load_dwordx4 v[60:63], %[offb], %[sb] offset:-30\n\t"
-#define MS_BODY8(RD)                                                     \
-    MS_LOADS8                                                            \
-    "s_waitcnt vmcnt(1)\n\t"                                             \
-    MS_G8(RD, "v56", "v57", "v58", "v59")                                \
-    "s_waitcnt vmcnt(0)\n\t"                                             \
-    MS_G8(RD, "v60", "v61", "v62", "v63")
-// three groups of four: the third group's entries are loaded while the first one's answers arrive (offb has
-// moved on by one group then)
-#define MS_BODY4(RD)                                                     \
-    "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-6\n\t"         \
-    "global_load_dwordx2 v[58:59], %[offb], %[sb] offset:-14\n\t"        \
-    "s_waitcnt vmcnt(1)\n\t"                                             \
-    MS_G4(RD, "v56", "v57", "global_load_dwordx2 v[56:57], %[offb], %[sb] offset:-14\n\t") \
-    "s_waitcnt vmcnt(1)\n\t"                                             \
-    MS_G4(RD, "v58", "v59", "")                                          \
-    "s_waitcnt vmcnt(0)\n\t"                                             \
-    MS_G4(RD, "v56", "v57", "")
-// (a wave-uniform pointer the compiler has kept in vector registers, back in scalar ones: an asm operand needs them there)
-__device__ __forceinline__ const uint16_t* uniform_ptr(const uint16_t* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ uint64_t uniform_mask(uint64_t m) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-#define MS_STEPS(NAME, BODY, OPS8, ...)                                                                                       \
-    template <bool HAS_Q>                                                                                                     \
-    __device__ __forceinline__ uint64_t NAME(SwG<HAS_Q>& s, const uint16_t* sb8, uint64_t walk) {                             \
-        uint64_t save, still;                                                                                                 \
-        sb8 = uniform_ptr(sb8);                                                                                               \
-        asm volatile("s_mov_b64 %[save], exec\n\t"                                                                            \
-                     "s_mov_b64 exec, %[walk]\n\t" BODY ".Lms_end%=:\n\t"                                                     \
-                     "s_waitcnt vmcnt(0)\n\t"                                                                                 \
-                     "s_mov_b64 %[still], exec\n\t"                                                                           \
-                     "s_mov_b64 exec, %[save]\n\t"                                                                            \
-                     : [offb] "+v"(s.offb), [a0] "+v"(s.a0), [a1] "+v"(s.a1), [a2] "+v"(s.a2), [a3] "+v"(s.a3), [t0] "+v"(s.t0), \
-                       [t1] "+v"(s.t1), [t2] "+v"(s.t2), [t3] "+v"(s.t3), OPS8 [save] "=&s"(save), [still] "=&s"(still)       \
-                     : [bb] "v"(s.bb2), [lowa] "v"(s.lowa2), [probe] "v"(s.probe), [endb] "v"(s.endb), [sb] "s"(sb8),         \
-                       [walk] "s"(walk)                                                                                       \
-                     : "vcc", "memory", "v56", "v57", "v58", "v59", ##__VA_ARGS__);                                           \
-        return still;                                                                                                         \
-    }
-#define MS_OPS8                                                                                                                   \
-    [a4] "+v"(s.a4), [a5] "+v"(s.a5), [a6] "+v"(s.a6), [a7] "+v"(s.a7), [t4] "+v"(s.t4), [t5] "+v"(s.t5), [t6] "+v"(s.t6), [t7] "+v"(s.t7),
-#define MS_OPS4
-MS_STEPS(ms_steps_pair8, MS_BODY8("ds_read_u16"), MS_OPS8, "v60", "v61", "v62", "v63")
-MS_STEPS(ms_steps_pair4, MS_BODY4("ds_read_u16"), MS_OPS4)
-MS_STEPS(ms_steps_key8, MS_BODY8("ds_read_u8"), MS_OPS8, "v60", "v61", "v62", "v63")
-MS_STEPS(ms_steps_key4, MS_BODY4("ds_read_u8"), MS_OPS4)
-
-#ifndef MI355_M3_W
-#define MI355_M3_W 8
-#endif
-#ifndef MI355_M3_DUAL
-#define MI355_M3_DUAL 1
-#endif
-static_assert(!MI355_M3_DUAL || MI355_M3_W == 8, "two fibres walk in groups of eight");  // (MI355_M3_DUAL = 2: with refill)
-#ifndef MI355_M4_W
-#define MI355_M4_W 4
-#endif
-static_assert((MI355_M3_W == 4 || MI355_M3_W == 8) && (MI355_M4_W == 4 || MI355_M4_W == 8), "groups of four or eight steps");
-
-// Where the lanes of `dropped` stopped in their last group of W steps: at the first probe that equals their key
+// Where the lanes of `dropped` stopped in their last group of eight steps: at the first probe that equals their key
 // (the compares of the step block shrank EXEC there) -> *any, the probe's address and how far offb is past its
 // entry; the other lanes left at the end of the group.
 // (probe keys and addresses BY VALUE: selects among the fields of a struct behind a reference become a load through a
@@ -1357,7 +967,6 @@ static_assert((MI355_M3_W == 4 || MI355_M3_W == 8) && (MI355_M4_W == 4 || MI355_
 struct MsGroup {
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, a0, a1, a2, a3, a4, a5, a6, a7, probe;
 };
-template <int W>
 __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, uint32_t* asel_out, uint32_t* back_out) {
     const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe);
     const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & ~e0m;
@@ -1366,44 +975,35 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & ~any;
     any |= e3m;
     uint32_t asel, back;
-    if (W == 8) {
-        const uint64_t e4m = __builtin_amdgcn_ballot_w64(st.t4 == st.probe) & ~any;
-        any |= e4m;
-        const uint64_t e5m = __builtin_amdgcn_ballot_w64(st.t5 == st.probe) & ~any;
-        any |= e5m;
-        const uint64_t e6m = __builtin_amdgcn_ballot_w64(st.t6 == st.probe) & ~any;
-        any |= e6m;
-        const uint64_t e7m = __builtin_amdgcn_ballot_w64(st.t7 == st.probe) & ~any;
-        any |= e7m;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e7m) ? st.a7 : st.a0;
-        back = __builtin_amdgcn_inverse_ballot_w64(e7m) ? 2u : 16u;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e6m) ? st.a6 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e6m) ? 4u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e5m) ? st.a5 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e5m) ? 6u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e4m) ? st.a4 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e4m) ? 8u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 10u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 12u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 14u : back;
-    } else {
-        asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : st.a0;
-        back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 2u : 8u;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 4u : back;
-        asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
-        back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 6u : back;
-    }
+    const uint64_t e4m = __builtin_amdgcn_ballot_w64(st.t4 == st.probe) & ~any;
+    any |= e4m;
+    const uint64_t e5m = __builtin_amdgcn_ballot_w64(st.t5 == st.probe) & ~any;
+    any |= e5m;
+    const uint64_t e6m = __builtin_amdgcn_ballot_w64(st.t6 == st.probe) & ~any;
+    any |= e6m;
+    const uint64_t e7m = __builtin_amdgcn_ballot_w64(st.t7 == st.probe) & ~any;
+    any |= e7m;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e7m) ? st.a7 : st.a0;
+    back = __builtin_amdgcn_inverse_ballot_w64(e7m) ? 2u : 16u;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e6m) ? st.a6 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e6m) ? 4u : back;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e5m) ? st.a5 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e5m) ? 6u : back;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e4m) ? st.a4 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e4m) ? 8u : back;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 10u : back;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 12u : back;
+    asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
+    back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 14u : back;
     *any_out = any;
     *asel_out = asel;
     *back_out = back;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_match3 with two batches per wave (MI355_M3_DUAL, the default): the pair table leaves one workgroup of 16
+// Two batches per wave: the pair table leaves one workgroup of 16
 // waves per CU -- four per SIMD, with more than half of the 128 vector registers each may use idle -- and at
 // four waves the kernel is bound by the latency of its dependent steps (table read -> compare -> next group;
 // entry load -> first group), not by any unit: vector ALU 72 %, LDS 50 %, TA 52 % busy.  So a wave walks TWO
@@ -1499,60 +1099,12 @@ __device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, ui
     const uint64_t e = (uint64_t)seg_end(sg, base + r) - base;
     return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
 }
-// the end of an epoch's walk (a macro: the loops above end in it)
-#define MI355_M3_UNPERMUTE \
-    if (Ms) { \
- /* The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position */ \
- /* they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for */ \
- /* 0.4 GB of M).  Now that the walk is over the pair table is not needed any more: its LDS takes the epoch's */ \
- /* results by position, and they leave as whole lines. */ \
-        uint32_t* const lm = reinterpret_cast<uint32_t*>(s_T); \
-        const uint32_t cnt = (uint32_t)((uint64_t)n - E < (uint64_t)WINDOW_SIZE ? (uint64_t)n - E : (uint64_t)WINDOW_SIZE); \
-        for (int pass = 0; pass < (HAS_Q ? 2 : 1); pass++) { \
-            const uint32_t* src = pass ? Mqs : Ms; \
-            uint32_t* dst = pass ? Mq : M; \
-            __syncthreads(); \
-            for (uint32_t j = tid; j < J; j += M3T) lm[(uint32_t)own[j] >> 1] = src[E + j]; \
-            if (tid < 2 && J + tid < cnt) lm[J + tid] = 0; /* the positions without a hash byte */ \
-            __syncthreads(); \
-            for (uint32_t i = tid * 4; i < cnt; i += M3T * 4) { \
-                if (i + 4 <= cnt) { \
-                    *reinterpret_cast<uint4*>(dst + E + i) = *reinterpret_cast<const uint4*>(lm + i); \
-                } else { \
-                    for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k]; \
-                } \
-            } \
- /* The epoch's table lies in LDS by position: the restart steps (k_adv, lz77.rs:305-547) of its positions are taken */ \
- /* here, where the table costs an LDS read and the vector ALUs wait for the stores -- all but the last ADV_HALO */ \
- /* positions of an epoch that has a successor (a step looks at most that far ahead): k_adv_tail does those. */ \
-            if (!HAS_Q && advg) { \
-                const bool last_ep = E + cnt >= (uint64_t)n; \
-                const uint32_t upto = last_ep ? cnt : (cnt > ADV_HALO ? cnt - ADV_HALO : 0u); \
-                const uint32_t one = sg.m == 1 ? rel_end(sg, E, 0) : 0u; \
-                const TileM tm{lm}; \
-                for (uint32_t i = tid * 4; i < upto; i += M3T * 4) { \
-                    uint16_t a4[4] = {0, 0, 0, 0}; \
-                    _Pragma("unroll") \
-                    for (uint32_t q = 0; q < 4; q++) \
-                        if (i + q < upto) a4[q] = (uint16_t)parse_step(tm, tm, i + q, sg.m == 1 ? one : rel_end(sg, E, i + q), pcfg).adv; \
-                    if (i + 4 <= upto) { \
-                        *reinterpret_cast<uint2*>(advg + E + i) = make_uint2((uint32_t)a4[0] | ((uint32_t)a4[1] << 16), (uint32_t)a4[2] | ((uint32_t)a4[3] << 16)); \
-                    } else { \
-                        for (uint32_t q = 0; q < 4 && i + q < upto; q++) advg[E + i + q] = a4[q]; \
-                    } \
-                } \
-            } \
-        } \
-    }
-#ifndef MI355_M3_T
-#define MI355_M3_T 16
-#endif
 template <bool HAS_Q>
 __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                                 uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
                                                 SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
-                                                uint32_t* __restrict__ Mqs, uint16_t* __restrict__ advg, ParseCfg pcfg) {
+                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
     __shared__ __attribute__((aligned(16))) uint4 s_T[M3_PAIRS / 8];  // T[k] = byte k | byte k+1 << 8, k from the window's start
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1610,13 +1162,16 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     M2_T0
+    uint32_t unordered = 0;
     // set a fibre up for batch b (all lanes call it: the lane masks it sets must be ballots of the whole wave)
-    auto set_up = [&](SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out) -> bool {
+    // (before0: the entry in front of the batch's first one, for the order check below)
+    auto set_up = [&](SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out, uint32_t before0, uint32_t* last_out) -> bool {
         const uint32_t j = b * 64 + lane;
         const bool valid = have && j < J;
-        uint32_t srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
+        uint32_t raw = 0, srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
         if (valid) {
-            srel = (uint32_t)own[j] >> 1;
+            raw = (uint32_t)own[j];
+            srel = raw >> 1;
             prel = bias + srel;
             const uint32_t v = win.load32(prel);
             const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
@@ -1628,16 +1183,26 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             nrel = lim(prel);
         }
+        // The chain order IS the order of the bucket's entries (nearest first = descending positions).  k_sort<1> takes
+        // a key's rank from the order in which the LDS serves the lanes of one atomic -- what the hardware does, not what
+        // the ISA promises (k_lds_order_test samples it when a context is made) -- so the property is checked on the data
+        // itself, for every entry and the one before it in its bucket: a violation could never corrupt a stream, but it
+        // would silently change which of two equally long matches wins.  The host then sorts again with ballot ranks.
+        // (The entry before a lane's own is the lane below's -- one shift of the wave; a load of own[j - 1] here cost 2.3 %
+        // of the kernel.)
+        const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)before0, (int)raw, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        unordered |= (valid && j > ob && before >= raw) ? 1u : 0u;
+        *last_out = (uint32_t)__builtin_amdgcn_readlane((int)raw, 63);
         (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
         st.done = ~st.walk;
         *srel_out = srel;
         return valid;
     };
     // settle the lanes of a fibre that left the last block
-    auto settle = [&](SwG<HAS_Q>& st, uint64_t dropped) {
+    auto settle = [&](auto run1, SwG<HAS_Q>& st, uint64_t dropped) {
         uint64_t any;
         uint32_t asel, back;
-        ms_decode<MI355_M3_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
+        ms_decode(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
                                       st.a6, st.a7, st.probe},
                               &any, &asel, &back);
         // a lane that used up its last segment without a hit has its result: only hits and the move to the
@@ -1645,316 +1210,72 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if ((any & dropped) | (dropped & st.has2)) {
             M2_CNT(2, 1)
             M2_CNT(3, __popcll(dropped))
-            swg_service(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
+            swg_service<decltype(run1)::value>(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
         }
     };
-#if MI355_M3_DUAL >= 2
-    // ---- lanes that take a new position when they have finished theirs (MI355_M3_DUAL=2; 3: one fibre per wave) ----------------------------
-    // A batch needs as many services as its busiest lane has events, and its tail walks with a few lanes: so a fibre is not
-    // a batch any more.  The next two batches are set up densely (64 lanes) and PARKED, twelve bytes per position, in the
-    // LDS the pair table leaves (slots A and B of the wave): srel | bucket bounds | first candidate.  A lane of either
-    // fibre that has finished takes the record of ITS lane number out of a slot (so lane l only ever works on entries
-    // l, l + 64, ... of the batches that pass), stores the result it holds, and is set up from the record -- once enough
-    // lanes of the fibre wait (MI355_M3_T) or nothing of it walks; its first candidate rides with the fibre's next service.
-    // A slot that is used up is parked anew, one phase per round of the loop, so that each phase's loads have a step
-    // block and two services to arrive in.
-    __shared__ uint32_t s_park[M3T / 64][2][3][64];
-    uint32_t* const Mo = Ms ? Ms : M;
-    uint32_t* const Mqo = Ms ? Mqs : Mq;
-    uint32_t* const pk = &s_park[tid >> 6][0][0][0];
-    const uint16_t* const sprev = own - WINDOW_SIZE;
-    // the pool is a queue: records qh .. qt - 1 wait, record i lies in slot (i / 64) % 2 at place i % 64; only the last
-    // batch of an epoch can be short, so every other one fills its 64 places
-    uint32_t qh = 0, qt = 0;
-    uint32_t batA = 0, batB = 0;    // the batch in slot 0 / 1
-    bool more = true;               // batches left to hand out
-    uint32_t ph = 0, qb = 0;        // the parking in progress: phase, batch, and what is in flight
-    uint32_t q_own = 0, q_prev = 0, q_ob = 0, q_pb0 = 0, q_pb1 = 0, q_first = 0;
-    auto advance = [&]() __attribute__((always_inline)) {
-        const uint32_t j = qb * 64 + lane;
-        const bool qv = j < J;
-        if (ph == 3) {
-            const uint32_t slot = (qt >> 6) & 1u;
-            uint32_t* const r = pk + slot * 192u + lane;
-            r[0] = q_own >> 1;
-            r[64] = q_ob | (q_pb0 << 16);
-            r[128] = q_pb1 | (q_first << 16);
-            if (slot == 0)
-                batA = qb;
-            else
-                batB = qb;
-            qt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(qv));
-            if (qt & 63u) more = false;  // (a short batch is the epoch's last)
-            wave_lds_fence();
-            ph = 0;
-        }
-        if (ph == 0) {
-            // (a slot is free once the queue's head has left it)
-            if (!more || qt - qh > 64u) return;
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&s_next, 1u);
-            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-            if (b >= b_hi) {
-                more = false;
-                return;
-            }
-            qb = b;
-            const uint32_t jn = b * 64 + lane;
-            q_own = jn < J ? (uint32_t)own[jn] : 0u;
-            q_prev = (jn < J && jn > 0) ? (uint32_t)own[jn - 1] : 0u;
-            M2_CNT(0, 1)
-            ph = 1;
-        } else if (ph == 1) {
-            const uint32_t srel = q_own >> 1;
-            const uint32_t v = win.load32(bias + srel);
-            const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
-            const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
-            q_ob = q_pb0 = q_pb1 = 0;
-            if (qv) {
-                q_ob = Bown[h];
-                if (e) {
-                    q_pb0 = Bprev[h];
-                    q_pb1 = Bprev[h + 1];
-                }
-            }
-            ph = 2;
-        } else {
-            // the first candidate: the entry before the lane's own in its bucket, else the last of the previous epoch's bucket
-            q_first = q_prev;
-            if (qv && j <= q_ob && q_pb1 > q_pb0) q_first = sprev[q_pb1 - 1];
-            ph = 3;
-        }
-    };
-    // Idle lanes `idle` of a fibre take the records at the head of the queue, in lane order: each stores the result it
-    // holds and is set up from its record.  Returns those with candidates: they "left at the first probe of a group" and
-    // go to the fibre's next service.
-    auto refill = [&](SwG<HAS_Q>& st, uint32_t& cur, uint32_t& fa, uint64_t idle) __attribute__((always_inline)) -> uint64_t {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-        const uint32_t avail = qt - qh;
-        const bool tk = __builtin_amdgcn_inverse_ballot_w64(idle) && rank < avail;
-        const uint64_t take = uniform_mask(__builtin_amdgcn_ballot_w64(tk));
-#ifndef MI355_M3_NOSTORE
-        {
-            uint32_t pm, pq;
-            swg_result(st, &pm, &pq);
-            if (tk && cur != ~0u) {
-                Mo[E + cur] = pm;
-                if (HAS_Q) Mqo[E + cur] = pq;
-            }
-        }
-#endif
-        const uint32_t idx = qh + rank;
-        const bool inA = ((idx >> 6) & 1u) == 0;
-        const uint32_t* const r = pk + (inA ? 0u : 192u) + (idx & 63u);
-        uint32_t r0 = 0, r1 = 0, r2 = 0;
-        if (tk) {
-            r0 = r[0];
-            r1 = r[64];
-            r2 = r[128];
-        }
-        const uint32_t jb = (inA ? batA : batB) * 64 + (idx & 63u);
-        uint32_t prel = bias, nrel = bias;  // (a lane that takes nothing: nothing to search)
-        if (tk) {
-            prel = bias + r0;
-            nrel = lim(prel);
-        }
-        SwG<HAS_Q> nw;
-        (void)swg_setup(nw, win, tk ? jb : 0u, r1 & 0xffffu, r1 >> 16, r2 & 0xffffu, prel, nrel, tbase, bias, checks, checks_q);
-        const uint64_t fst = uniform_mask(nw.walk & take);
-        const bool fs = __builtin_amdgcn_inverse_ballot_w64(fst);
-#define MI355_MRG(F) st.F = tk ? nw.F : st.F;
-        MI355_MRG(offb) MI355_MRG(endb) MI355_MRG(bb2) MI355_MRG(lowa2) MI355_MRG(probe) MI355_MRG(prel) MI355_MRG(maxlen)
-        MI355_MRG(p16[0]) MI355_MRG(p16[1]) MI355_MRG(p16[2]) MI355_MRG(p16[3]) MI355_MRG(bm1) MI355_MRG(bestd) MI355_MRG(low)
-        MI355_MRG(offb2) MI355_MRG(endb2) MI355_MRG(seg0) MI355_MRG(vbase) MI355_MRG(mq)
-#undef MI355_MRG
-        fa = fs ? (r2 >> 16) + st.bb2 : fa;  // (the probe address of the first candidate; its entry is the one at offb)
-        // (wave-uniform all of them, which the compiler does not see: as lane values they would live in vector registers)
-        st.walk = uniform_mask(st.walk & ~take);
-        st.done = uniform_mask((st.done & ~take) | (~nw.walk & take));
-        st.in_prev = uniform_mask((st.in_prev & ~take) | (nw.in_prev & take));
-        st.hq = uniform_mask((st.hq & ~take) | (nw.hq & take));
-        st.has2 = uniform_mask((st.has2 & ~take) | (nw.has2 & take));
-        cur = tk ? (Ms ? jb : r0) : cur;
-        qh += (uint32_t)__popcll(take);
-        M2_T(8)
-        return fst;
-    };
-    SwG<HAS_Q> sx, sy;
-    {
-        SwG<HAS_Q> z;
-        (void)swg_setup(z, win, 0u, 0u, 0u, 0u, bias, bias, tbase, bias, checks, checks_q);  // a fibre without positions
-        z.walk = 0;
-        z.done = ~0ull;
-        sx = z;
-        sy = z;
-    }
-    uint32_t curx = ~0u, cury = ~0u, fax = 0, fay = 0;
-    // What a fibre's service needs of the lanes that left the last block and of those set up since the last service (their
-    // first candidate has "left at a probe"): read off the probe answers of BOTH fibres before either is served, so that
-    // neither fibre's sixteen are live during a service.
-    auto decode2 = [&](SwG<HAS_Q>& st, uint64_t dropped, uint64_t first, uint32_t fa, uint64_t* hits, uint32_t* asel_out,
-                       uint32_t* ho_out) __attribute__((always_inline)) {
-        uint64_t any;
-        uint32_t asel, back;
-        ms_decode<MI355_M3_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
-                                      st.a6, st.a7, st.probe},
-                              &any, &asel, &back);
-        const bool pf = __builtin_amdgcn_inverse_ballot_w64(first);
-        *asel_out = pf ? fa : asel;
-        *ho_out = st.offb + (pf ? 0u : back);
-        *hits = uniform_mask((any & dropped) | first);
-    };
-    auto serve2 = [&](SwG<HAS_Q>& st, uint64_t all, uint64_t hits, uint32_t asel, uint32_t ho) __attribute__((always_inline)) {
-        if (hits | (all & st.has2)) {
-            M2_CNT(2, 1)
-            M2_CNT(3, __popcll(all))
-            swg_service(st, win, tbase, checks_q, all, hits, asel, ho);
-        }
-    };
-    // the first two batches are parked before anything walks
-    do advance(); while (ph != 0 || (more && qt - qh <= 64u));
-#if MI355_M3_DUAL == 3
-    (void)sy;
-    (void)cury;
-    (void)fay;
-    for (;;) {
-        sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);
-        sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);
-        qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);
-        qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
-        const uint64_t wx = sx.walk;
-        uint64_t dx = 0;
-        if (wx) {
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(wx))
-            const uint64_t cx = ms_steps_pair8(sx, sbase - 4, wx);
-            M2_T(12)
-            sx.walk = cx;
-            dx = wx & ~cx;
-        }
-        uint64_t hx = 0;
-        uint32_t ax = 0, ox = 0;
-        if (dx) decode2(sx, dx, 0, 0u, &hx, &ax, &ox);
-        advance();
-        uint64_t fx = 0;
-        {
-            const uint64_t t = ~(sx.walk | dx);
-            const uint32_t av = qt - qh;
-            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
-                fx = refill(sx, curx, fax, t);
-                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fx);
-                ax = pf ? fax : ax;
-                ox = pf ? sx.offb : ox;
-            }
-        }
-        sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);
-        sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);
-        qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);
-        qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
-        fx = uniform_mask(fx);
-        hx = uniform_mask(hx);
-        if (dx | fx) serve2(sx, dx | fx, hx | fx, ax, ox);
-        M2_T(9)
-        if (sx.walk == 0 && !more && ph == 0 && qt == qh) break;
-    }
-#else
-#define MI355_UNI_MASKS                                                                                             \
-    sx.walk = uniform_mask(sx.walk); sx.done = uniform_mask(sx.done); sx.in_prev = uniform_mask(sx.in_prev);        \
-    sx.hq = uniform_mask(sx.hq); sx.has2 = uniform_mask(sx.has2);                                                   \
-    sy.walk = uniform_mask(sy.walk); sy.done = uniform_mask(sy.done); sy.in_prev = uniform_mask(sy.in_prev);        \
-    sy.hq = uniform_mask(sy.hq); sy.has2 = uniform_mask(sy.has2);                                                   \
-    qh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qh);                                                         \
-    qt = (uint32_t)__builtin_amdgcn_readfirstlane((int)qt);
-    for (;;) {
-        // (the lane masks are wave-uniform, which the compiler loses sight of around the loop and behind a conditional
-        // refill: as lane values they would live in vector registers, two each)
-        MI355_UNI_MASKS
-        const uint64_t wx = sx.walk, wy = sy.walk;
-        uint64_t dx = 0, dy = 0;
-        if (wx | wy) {
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(wx) + __popcll(wy))
-            uint64_t cx, cy;
-            ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
-            M2_T(12)
-            sx.walk = cx;
-            sy.walk = cy;
-            dx = wx & ~cx;
-            dy = wy & ~cy;
-        }
-        uint64_t hx = 0, hy = 0;
-        uint32_t ax = 0, ay = 0, ox = 0, oy = 0;
-        if (dx) decode2(sx, dx, 0, 0u, &hx, &ax, &ox);
-        if (dy) decode2(sy, dy, 0, 0u, &hy, &ay, &oy);
-        // Parking and refill come here: no group of probes is live any more, and what they load and store has the two
-        // services to arrive in (the step block's waits count every memory operation of the wave).
-        advance();
-        uint64_t fx = 0, fy = 0;
-        {
-            const uint64_t t = ~(sx.walk | dx);
-            const uint32_t av = qt - qh;  // (a refill for a handful of records is not worth its price unless they are the last)
-            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
-                fx = refill(sx, curx, fax, t);
-                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fx);
-                ax = pf ? fax : ax;
-                ox = pf ? sx.offb : ox;
-            }
-        }
-        {
-            const uint64_t t = ~(sy.walk | dy);
-            const uint32_t av = qt - qh;
-            if (av && (((uint32_t)__popcll(t) >= (uint32_t)MI355_M3_T && (av >= (uint32_t)MI355_M3_T || (!more && ph == 0))) || t == ~0ull)) {
-                fy = refill(sy, cury, fay, t);
-                const bool pf = __builtin_amdgcn_inverse_ballot_w64(fy);
-                ay = pf ? fay : ay;
-                oy = pf ? sy.offb : oy;
-            }
-        }
-        MI355_UNI_MASKS
-        fx = uniform_mask(fx);
-        fy = uniform_mask(fy);
-        hx = uniform_mask(hx);
-        hy = uniform_mask(hy);
-        if (dx | fx) serve2(sx, dx | fx, hx | fx, ax, ox);
-        if (dy | fy) serve2(sy, dy | fy, hy | fy, ay, oy);
-        M2_T(9)
-        if ((sx.walk | sy.walk) == 0 && !more && ph == 0 && qt == qh) break;
-    }
-#undef MI355_UNI_MASKS
-#endif
-#ifndef MI355_M3_NOSTORE
-    {
-        uint32_t pm, pq;
-        swg_result(sx, &pm, &pq);
-        if (curx != ~0u) {
-            Mo[E + curx] = pm;
-            if (HAS_Q) Mqo[E + curx] = pq;
-        }
-        swg_result(sy, &pm, &pq);
-        if (cury != ~0u) {
-            Mo[E + cury] = pm;
-            if (HAS_Q) Mqo[E + cury] = pq;
-        }
-    }
-    MI355_M3_UNPERMUTE
-#endif
-#elif MI355_M3_DUAL
     uint32_t* const Mo = Ms ? Ms : M;      // where a batch's results go: in the order of S_e (turned round at the end), else by position
     uint32_t* const Mqo = Ms ? Mqs : Mq;
-    uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 2u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= b_hi) break;
-        SwG<HAS_Q> sx, sy;
-        uint32_t srx, sry;
-        const bool vx = set_up(sx, b, true, &srx);
-        const bool vy = set_up(sy, b + 1, b + 1 < b_hi, &sry);
-        M2_CNT(0, 2)
-        M2_T(8)
-#ifndef MI355_M3_NOSTORE
-        // (the results of the pair before go out here, behind this pair's set-up loads: see k_match2)
+    // The walk of the workgroup's batches, in two instantiations: RUN1 is the service with the one-sided long compare
+    // (stages.h swg_service) for epochs that k_sort found to consist of runs of one byte -- zero fill and the like, where
+    // every position's first candidate is its neighbour and matches to the end -- and costs the other epochs nothing.
+    auto walk_all = [&](auto run1) {
+        constexpr bool RUN1 = decltype(run1)::value;
+        uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
+        for (;;) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&s_next, 2u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b >= b_hi) break;
+            SwG<HAS_Q> sx, sy;
+            uint32_t srx, sry;
+            // (the entry in front of the pair's first one: a scalar load -- b is the same for the whole wave)
+            uint32_t lastx, lasty;
+            const uint32_t front = b ? (uint32_t)own[(uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 64 - 1))] : 0u;
+            const bool vx = set_up(sx, b, true, &srx, front, &lastx);
+            const bool vy = set_up(sy, b + 1, b + 1 < b_hi, &sry, lastx, &lasty);
+            (void)lasty;
+            M2_CNT(0, 2)
+            M2_T(8)
+            // (the results of the pair before go out here, behind this pair's set-up loads)
+            if (pxat != ~0u) {
+                Mo[E + pxat] = pxm;
+                if (HAS_Q) Mqo[E + pxat] = pxq;
+            }
+            if (pyat != ~0u) {
+                Mo[E + pyat] = pym;
+                if (HAS_Q) Mqo[E + pyat] = pyq;
+            }
+            // the first candidate of every lane goes straight to the service
+            // (no finding out where they stopped: every lane concerned "left at the first probe of its group")
+            {
+                const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
+                if (dx) swg_service<RUN1>(sx, win, tbase, checks_q, dx, dx, sx.a0, sx.offb + 16u);
+                if (dy) swg_service<RUN1>(sy, win, tbase, checks_q, dy, dy, sy.a0, sy.offb + 16u);
+                M2_CNT(2, 2)
+                M2_CNT(3, __popcll(dx) + __popcll(dy))
+                M2_T(9)
+            }
+            for (;;) {
+                const uint64_t wx = sx.walk, wy = sy.walk;
+                if ((wx | wy) == 0) break;
+                M2_CNT(1, 1)
+                M2_CNT(7, __popcll(wx) + __popcll(wy))
+                uint64_t cx, cy;
+                ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
+                M2_T(12)
+                sx.walk = cx;
+                sy.walk = cy;
+                const uint64_t dx = wx & ~cx, dy = wy & ~cy;
+                if (dx) settle(run1, sx, dx);
+                if (dy) settle(run1, sy, dy);
+                M2_T(9)
+            }
+            swg_result(sx, &pxm, &pxq);
+            swg_result(sy, &pym, &pyq);
+            pxat = vx ? (Ms ? b * 64 + lane : srx) : ~0u;
+            pyat = vy ? (Ms ? b * 64 + 64 + lane : sry) : ~0u;
+            M2_T(13)
+        }
         if (pxat != ~0u) {
             Mo[E + pxat] = pxm;
             if (HAS_Q) Mqo[E + pxat] = pxq;
@@ -1963,496 +1284,39 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             Mo[E + pyat] = pym;
             if (HAS_Q) Mqo[E + pyat] = pyq;
         }
-#endif
-        // the first candidate of every lane goes straight to the service
-        // (no finding out where they stopped: every lane concerned "left at the first probe of its group")
-#ifdef MI355_M3_NEIGHBOUR
-        // The first candidate of the position at entry j of its bucket is the position at entry j - 1: the lane below, whose
-        // sixteen bytes sit in ITS registers -- one shift of the wave hands them up, where load16 was five 8-byte reads of the
-        // pair table and nine byte selects.  The lanes it cannot serve (lane 0, and the first entry of a bucket, whose first
-        // candidate lies in the previous epoch's) keep the state swg_first gave them -- "left at the first probe" -- and are
-        // settled with the lanes that leave the first block.
-        // (Which lanes wait to be settled needs no book-keeping: they are the ones that neither walk nor are done.)
-        {
-            const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
-            const uint64_t fx = dx & ~sx.in_prev & ~1ull, fy = dy & ~sy.in_prev & ~1ull;
-            if (fx) {
-                uint32_t q[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) q[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sx.p16[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                swg_service(sx, win, tbase, checks_q, fx, fx, sx.a0, sx.offb + 16u, q);
-            }
-            if (fy) {
-                uint32_t q[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) q[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy.p16[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                swg_service(sy, win, tbase, checks_q, fy, fy, sy.a0, sy.offb + 16u, q);
-            }
-            M2_CNT(2, 2)
-            M2_CNT(3, __popcll(fx) + __popcll(fy))
-            M2_T(9)
-        }
-        for (;;) {
-            const uint64_t wx = sx.walk, wy = sy.walk;
-            if (wx | wy) {
-                M2_CNT(1, 1)
-                M2_CNT(7, __popcll(wx) + __popcll(wy))
-                uint64_t cx, cy;
-                ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
-                M2_T(12)
-                sx.walk = cx;
-                sy.walk = cy;
-            }
-            const uint64_t dx = ~(sx.walk | sx.done), dy = ~(sy.walk | sy.done);
-            if ((wx | wy | dx | dy) == 0) break;
-            if (dx) settle(sx, dx);
-            if (dy) settle(sy, dy);
-            // (a lane that merely ran out of candidates is not serviced: whoever does not walk now has its result)
-            sx.done |= dx & ~sx.walk;
-            sy.done |= dy & ~sy.walk;
-            M2_T(9)
-        }
-#else
-        {
-            const uint64_t dx = swg_first(sx, win, 8u), dy = swg_first(sy, win, 8u);
-            if (dx) swg_service(sx, win, tbase, checks_q, dx, dx, sx.a0, sx.offb + 16u);
-            if (dy) swg_service(sy, win, tbase, checks_q, dy, dy, sy.a0, sy.offb + 16u);
-            M2_CNT(2, 2)
-            M2_CNT(3, __popcll(dx) + __popcll(dy))
-            M2_T(9)
-        }
-        for (;;) {
-            const uint64_t wx = sx.walk, wy = sy.walk;
-            if ((wx | wy) == 0) break;
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(wx) + __popcll(wy))
-            uint64_t cx, cy;
-            ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
-            M2_T(12)
-            sx.walk = cx;
-            sy.walk = cy;
-            const uint64_t dx = wx & ~cx, dy = wy & ~cy;
-            if (dx) settle(sx, dx);
-            if (dy) settle(sy, dy);
-            M2_T(9)
-        }
-#endif
-        swg_result(sx, &pxm, &pxq);
-        swg_result(sy, &pym, &pyq);
-        pxat = vx ? (Ms ? b * 64 + lane : srx) : ~0u;
-        pyat = vy ? (Ms ? b * 64 + 64 + lane : sry) : ~0u;
-        M2_T(13)
-    }
-#ifndef MI355_M3_NOSTORE
-    if (pxat != ~0u) {
-        Mo[E + pxat] = pxm;
-        if (HAS_Q) Mqo[E + pxat] = pxq;
-    }
-    if (pyat != ~0u) {
-        Mo[E + pyat] = pym;
-        if (HAS_Q) Mqo[E + pyat] = pyq;
-    }
-    MI355_M3_UNPERMUTE
-#endif
-#else
-    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= b_hi) break;
-        SwG<HAS_Q> st;
-        uint32_t srel;
-        const bool valid = set_up(st, b, true, &srel);
-        M2_CNT(0, 1)
-        M2_T(8)
-#ifndef MI355_M3_NOSTORE
-        if (pend_at != ~0u) {  // (the results of the batch before, behind this batch's set-up loads: see k_match2)
-            M[E + pend_at] = pend_m;
-            if (HAS_Q) Mq[E + pend_at] = pend_mq;
-        }
-#endif
-        uint64_t dropped = swg_first(st, win, (uint32_t)MI355_M3_W);  // the first candidate goes straight to the service
-        for (;;) {
-            if (dropped) settle(st, dropped);
-            M2_T(9)
-            const uint64_t walk = st.walk;
-            if (walk == 0) break;
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(walk))
-            const uint64_t still = MI355_M3_W == 8 ? ms_steps_pair8(st, sbase - 4, walk) : ms_steps_pair4(st, sbase - 4, walk);
-            M2_T(12)
-            st.walk = still;
-            dropped = walk & ~still;
-        }
-        swg_result(st, &pend_m, &pend_mq);
-        pend_at = valid ? srel : ~0u;
-        M2_T(13)
-    }
-#ifndef MI355_M3_NOSTORE
-    if (pend_at != ~0u) {
-        M[E + pend_at] = pend_m;
-        if (HAS_Q) Mq[E + pend_at] = pend_mq;
-    }
-#endif
-#endif
-#ifdef MI355_MATCH_STATS
-    if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
-#endif
-}
-
-#include "match_queue.inc"
-
-// ---------------------------------------------------------------------------------------------
-// k_match4: the walk of k_match3 (stages.h SwG) over a table that fits the CU twice.  The probe never needs the
-// two bytes themselves, only something that is equal whenever they are: LDS holds ONE byte per position, an
-// 8-bit key of the pair (byte k, byte k+1) (stages.h pair_key8) -- 64 KB for the previous and the own epoch,
-// so two workgroups (8 waves per SIMD) share a CU again, as in k_match2, while a visit stays one LDS read and
-// two vector instructions.  A candidate whose key matches by chance (1 in 256) is compared and dropped like any
-// other the reference's probe passes in vain.  The bytes of a compare -- 16 of the candidate, once per hit; 16
-// of the position, once at set-up -- come from global memory (the input is resident in L2 / the Infinity
-// Cache), and the lane's next probe key is read from the table at its own position + best - 1.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t M4T = 1024;
-constexpr uint32_t M4_BYTES = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16
-
-struct KeyWin {
-    enum : uint32_t { SH = 0 };
-    const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array
-    uint32_t tbase;      // LDS address of the key of window position 0
-    const uint8_t* wp;   // global: the window's first byte
-    uint32_t nw;         // bytes of input from wp on
-    typedef __attribute__((address_space(3))) const uint8_t* lds_u8;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __device__ uint32_t key_at(uint32_t a) const { return *(lds_u8)a; }
-    __device__ void load16(uint32_t pos, uint32_t* q) const {
-        if (nw >= 16 && pos <= nw - 16) {  // (the hardware takes a 16-byte load at any byte address; `pos` may be anything)
-            u32x4 v;
-            __builtin_memcpy(&v, wp + pos, 16);
-            q[0] = v.x;
-            q[1] = v.y;
-            q[2] = v.z;
-            q[3] = v.w;
-        } else {  // the last bytes of the input, or an address that means nothing (a lane that has nothing to compare)
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // (named: a loop over q[] would put it in scratch memory)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if (pos + b < nw) r0 |= (uint32_t)wp[pos + b] << (8 * b);
-                if (pos + 4 + b < nw) r1 |= (uint32_t)wp[pos + 4 + b] << (8 * b);
-                if (pos + 8 + b < nw) r2 |= (uint32_t)wp[pos + 8 + b] << (8 * b);
-                if (pos + 12 + b < nw) r3 |= (uint32_t)wp[pos + 12 + b] << (8 * b);
-            }
-            q[0] = r0;
-            q[1] = r1;
-            q[2] = r2;
-            q[3] = r3;
-        }
-    }
-    __device__ uint32_t load32(uint32_t pos) const {
-        uint32_t v = 0;
-        if (nw >= 4 && pos <= nw - 4) {
-            __builtin_memcpy(&v, wp + pos, 4);
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (pos + b < nw) v |= (uint32_t)wp[pos + b] << (8 * b);
-        }
-        return v;
-    }
-    __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
-};
-
-template <bool HAS_Q>
-__global__ __launch_bounds__(M4T, 8) void k_match4(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
-                                                   const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
-                                                   uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
-                                                   SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split) {
-    __shared__ __attribute__((aligned(16))) uint4 s_K[M4_BYTES / 16];  // key of (byte k, byte k+1), k from the window's start
-    __shared__ uint32_t s_next;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
-    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
-    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
-    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
-    // stage the keys: 16 bytes and the byte behind them make 16 keys = one 16-byte store
-    for (uint32_t w = tid; w < wbytes / 16; w += M4T) {
-        const uint64_t g = wbase + 16ull * w;
-        uint32_t t[5] = {0, 0, 0, 0, 0};
-        if (in_aligned16 && g + 20 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4*>(in + g);
-            t[0] = v.x;
-            t[1] = v.y;
-            t[2] = v.z;
-            t[3] = v.w;
-            t[4] = *reinterpret_cast<const uint32_t*>(in + g + 16);
-        } else {
-            for (int b = 0; b < 17; b++)
-                if (g + b < n) t[b >> 2] |= (uint32_t)in[g + b] << (8 * (b & 3));
-        }
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // pair_key8 on four pairs at once: x ^ (y << 3) ^ (y >> 5) per byte, y = the bytes one place on
-            const uint32_t x = t[k], y = __builtin_amdgcn_alignbyte(t[k + 1], t[k], 1);
-            o[k] = x ^ ((y << 3) & 0xf8f8f8f8u) ^ ((y >> 5) & 0x07070707u);
-        }
-        s_K[w] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    const uint32_t J = epoch_active(n, E);
-    const uint32_t nbat = (J + 63) / 64;
-    const uint32_t b_lo = (uint32_t)((uint64_t)nbat * part / split), b_hi = (uint32_t)((uint64_t)nbat * (part + 1) / split);
-    if (tid == 0) s_next = b_lo;
-    if (part == 0 && tid < 2) {  // the positions without a hash byte (the last two of the input) are never searched
-        const uint64_t p = E + J + tid;
-        if (p < n && p < E + WINDOW_SIZE) {
-            M[p] = 0;
-            if (HAS_Q) Mq[p] = 0;
-        }
-    }
-    __syncthreads();
-    const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_K;
-    const uint32_t bias = (uint32_t)(E - wbase);  // position of the own epoch's first byte in the window
-    const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;  // (see k_match3)
-    KeyWin win{sbase, tbase, in + wbase, (uint32_t)(n - wbase)};
-    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
-    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
-    const uint16_t* Bprev = Bown - BSTRIDE;
-    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
-#ifdef MI355_MATCH_STATS
-    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    M2_T0
-    uint32_t pend_at = ~0u, pend_m = 0, pend_mq = 0;
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= b_hi) break;
-        const uint32_t j = b * 64 + lane;
-        const bool valid = j < J;
-        SwG<HAS_Q> st;
-        uint32_t srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
-        uint32_t hv = 0;
-        if (valid) {
-            srel = own[j];
-            prel = bias + srel;
-            hv = win.load32(prel);
-        }
-        if (valid) {
-            const uint32_t ab = rewarm_ab(ov, E + srel, hv & 0xff, (hv >> 8) & 0xff);
-            const uint32_t h = hash3(ab & 0xff, ab >> 8, (hv >> 16) & 0xff);
-            ob = Bown[h];
-            if (e) {
-                pb0 = Bprev[h];
-                pb1 = Bprev[h + 1];
-            }
-            nrel = lim(prel);
-        }
-        // (one call for all lanes: the lane masks it sets must be ballots of the whole wave)
-        (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
-        st.done = ~st.walk;
-        M2_CNT(0, 1)
-        M2_T(8)
-        if (pend_at != ~0u) {  // (the results of the batch before, behind this batch's set-up loads: see k_match2)
-            M[E + pend_at] = pend_m;
-            if (HAS_Q) Mq[E + pend_at] = pend_mq;
-        }
-        uint64_t dropped = swg_first(st, win, (uint32_t)MI355_M4_W);  // the first candidate goes straight to the service
-        for (;;) {
-            if (dropped) {
-                uint64_t any;
-                uint32_t asel, back;
-                ms_decode<MI355_M4_W>(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
-                                              st.a6, st.a7, st.probe},
-                                      &any, &asel, &back);
-                if ((any & dropped) | (dropped & st.has2)) {  // (see k_match3)
-                    M2_CNT(2, 1)
-                    M2_CNT(3, __popcll(dropped))
-                    swg_service(st, win, tbase, checks_q, dropped, any & dropped, asel, st.offb + back);
-                }
-                M2_T(9)
-            }
-            const uint64_t walk = st.walk;
-            if (walk == 0) break;
-            M2_CNT(1, 1)
-            M2_CNT(7, __popcll(walk))
-            const uint64_t still = MI355_M4_W == 8 ? ms_steps_key8(st, sbase - 4, walk) : ms_steps_key4(st, sbase - 4, walk);
-            M2_T(12)
-            st.walk = still;
-            dropped = walk & ~still;
-        }
-        swg_result(st, &pend_m, &pend_mq);
-        pend_at = valid ? srel : ~0u;
-        M2_T(13)
-    }
-    if (pend_at != ~0u) {
-        M[E + pend_at] = pend_m;
-        if (HAS_Q) Mq[E + pend_at] = pend_mq;
-    }
-#ifdef MI355_MATCH_STATS
-    if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_match_coop: the wave-cooperative form of matching.rs:87-166 the north star describes -- ONE position
-// per wave, 64 lanes = 64 consecutive candidates of its chain (S makes the k-th candidate an array index),
-// probe and compare per lane, the first longest by ballot -- kept as a measured alternative
-// (MI355_MATCH_PATH=3; DESIGN.md has the numbers): a wave-instruction serves one position here and 64 of
-// them in k_match2, so it only pays where chains are hundreds of candidates long.
-// ---------------------------------------------------------------------------------------------
-template <bool HAS_Q>
-__global__ __launch_bounds__(M2T, 8) void k_match_coop(const uint8_t* __restrict__ in, uint32_t n,
-                                                       const uint16_t* __restrict__ Sg, const uint16_t* __restrict__ Bg,
-                                                       uint32_t* __restrict__ M, uint32_t* __restrict__ Mq, uint32_t checks,
-                                                       uint32_t checks_q, int in_aligned16, SegEnds sg, HashOverride ov,
-                                                       uint32_t e0) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_by[M2_BYTES];
-    __shared__ uint32_t s_next;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t e = e0 + blockIdx.x;
-    const uint64_t E = (uint64_t)e * WINDOW_SIZE;
-    const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
-    const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
-    uint32_t* sb32 = reinterpret_cast<uint32_t*>(s_by);
-    for (uint32_t w = tid; w < wbytes / 4; w += M2T) {
-        const uint64_t g = wbase + 4ull * w;
-        uint32_t v = 0;
-        if (in_aligned16 && g + 4 <= n) {
-            v = *reinterpret_cast<const uint32_t*>(in + g);
-        } else {
-            for (int b = 0; b < 4; b++)
-                if (g + b < n) v |= (uint32_t)in[g + b] << (8 * b);
-        }
-        sb32[w] = v;
-    }
-    const uint32_t J = epoch_active(n, E);
-    if (tid == 0) s_next = 0;
-    if (tid < 2) {
-        const uint64_t p = E + J + tid;
-        if (p < n && p < E + WINDOW_SIZE) {
-            M[p] = 0;
-            if (HAS_Q) Mq[p] = 0;
-        }
-    }
-    __syncthreads();
-    const uint32_t org = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_by;
-    const uint32_t bias = org + (uint32_t)(E - wbase);
-    SortWin win{Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE};
-    const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
-    const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
-    const uint16_t* Bprev = Bown - BSTRIDE;
-    TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
-    for (uint32_t guard_o = 0; guard_o < 40000; guard_o++) {
-        uint32_t j = 0;
-        if (lane == 0) j = atomicAdd(&s_next, 1u);
-        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-        if (j >= J) break;
-        // everything about the position is the same in all lanes
-        const uint32_t srel = own[j];
-        const uint32_t prel = bias + srel;
-        const uint32_t v = win.load32(prel);
-        const uint32_t ab = rewarm_ab(ov, E + srel, v & 0xff, (v >> 8) & 0xff);
-        const uint32_t h = hash3(ab & 0xff, ab >> 8, (v >> 16) & 0xff);
-        const uint32_t nrel = org + lim(prel - org);
-        uint32_t m = 0, mq = 0;
-        bool hq = HAS_Q && checks_q == 0;
-        if (prel + 2 < nrel && checks > 0) {
-            const uint32_t left0 = nrel - prel;
-            const uint32_t maxlen = left0 < (uint32_t)MAX_MATCH ? left0 : (uint32_t)MAX_MATCH;
-            const uint32_t low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
-            uint32_t p16[4];
-            win.load128(prel, p16);
-            uint32_t best = 1, bestd = 0, probe = p16[0] & 0xffffu;
-            uint32_t left = checks, qleft = checks_q;
-            bool done = false;
-            for (int phase = 0; phase < 2 && !done && left; phase++) {
-                int32_t top, lo;       // candidate indices top, top-1, ..., lo of this phase
-                uint32_t cb;           // coordinate of the phase's epoch
-                if (phase == 0) {
-                    top = (int32_t)(SW_OWN + j) - 1;
-                    lo = (int32_t)(SW_OWN + Bown[h]);
-                    cb = bias;
+    };
+    if (__builtin_amdgcn_readfirstlane((int)Bown[WINDOW_SIZE + 1]))
+        walk_all(std::true_type{});
+    else
+        walk_all(std::false_type{});
+    if (__builtin_amdgcn_ballot_w64(unordered != 0) != 0 && lane == 0) atomicOr(sort_bad, 1u);
+    if (Ms) {
+        // The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position
+        // they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for
+        // 0.4 GB of M).  Now that the walk is over the pair table is not needed any more: its LDS takes the epoch's
+        // results by position, and they leave as whole lines.
+        uint32_t* const lm = reinterpret_cast<uint32_t*>(s_T);
+        const uint32_t cnt = (uint32_t)((uint64_t)n - E < (uint64_t)WINDOW_SIZE ? (uint64_t)n - E : (uint64_t)WINDOW_SIZE);
+        for (int pass = 0; pass < (HAS_Q ? 2 : 1); pass++) {
+            const uint32_t* src = pass ? Mqs : Ms;
+            uint32_t* dst = pass ? Mq : M;
+            __syncthreads();
+            for (uint32_t j = tid; j < J; j += M3T) lm[(uint32_t)own[j] >> 1] = src[E + j];
+            if (tid < 2 && J + tid < cnt) lm[J + tid] = 0;  // the positions without a hash byte
+            __syncthreads();
+            for (uint32_t i = tid * 4; i < cnt; i += M3T * 4) {
+                if (i + 4 <= cnt) {
+                    *reinterpret_cast<uint4*>(dst + E + i) = *reinterpret_cast<const uint4*>(lm + i);
                 } else {
-                    if (!e) break;
-                    top = (int32_t)Bprev[h + 1] - 1;
-                    lo = (int32_t)Bprev[h];
-                    cb = org;
-                }
-                uint32_t guard_w = 0;
-                while (top >= lo && left && !done && ++guard_w < 4096) {
-                    uint32_t take = (uint32_t)(top - lo + 1);
-                    take = take < 64 ? take : 64;
-                    take = take < left ? take : left;
-                    if (HAS_Q && !hq) take = take < qleft ? take : qleft;
-                    const bool mine = lane < take;
-                    const uint32_t c = mine ? cb + win.sidx((uint32_t)(top - (int32_t)lane)) : prel;
-                    const bool inwin = mine && c >= low;  // matching.rs:102-106,127
-                    const uint64_t wmask = __builtin_amdgcn_ballot_w64(inwin);
-                    const bool hit = inwin && (win.load32(c + best - 1) & 0xffffu) == probe;  // :141-143
-                    uint32_t len = 0;
-                    if (__builtin_amdgcn_ballot_w64(hit)) {
-                        if (hit) {  // get_match_length :67-72
-                            uint32_t q[4];
-                            win.load128(c, q);
-                            const uint64_t z0 = ((uint64_t)(q[1] ^ p16[1]) << 32) | (uint64_t)(q[0] ^ p16[0]);
-                            const uint64_t z1 = ((uint64_t)(q[3] ^ p16[3]) << 32) | (uint64_t)(q[2] ^ p16[2]);
-                            len = z0 ? ((uint32_t)__builtin_ctzll(z0) >> 3) : (z1 ? 8u + ((uint32_t)__builtin_ctzll(z1) >> 3) : 16u);
-                            uint32_t guard_l = 0;
-                            while (len >= 16 && len < maxlen && ++guard_l < 64) {
-                                const uint64_t x = ((uint64_t)(win.load32(prel + len + 4) ^ win.load32(c + len + 4)) << 32) |
-                                                   (uint64_t)(win.load32(prel + len) ^ win.load32(c + len));
-                                if (x) {
-                                    len += (uint32_t)__builtin_ctzll(x) >> 3;
-                                    break;
-                                }
-                                len += 8;
-                            }
-                            len = len < maxlen ? len : maxlen;
-                        }
-                        // the longest of the chunk, the first (most recent) among equals: matching.rs:149-156
-                        uint32_t mx = len;
-#pragma unroll
-                        for (int off = 32; off; off >>= 1) {
-                            const uint32_t y = __shfl_xor(mx, off, 64);
-                            mx = mx > y ? mx : y;
-                        }
-                        if (mx > best) {
-                            const uint64_t who = __builtin_amdgcn_ballot_w64(hit && len == mx);
-                            const uint32_t first = (uint32_t)__builtin_ctzll(who);
-                            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)first);
-                            best = mx;
-                            bestd = prel - cc;
-                            if (mx == maxlen) {
-                                // (the reference stops at this candidate; candidates after it in the chunk were never visited)
-                                done = true;
-                            } else {
-                                probe = win.load32(prel + best - 1) & 0xffffu;
-                            }
-                        }
-                    }
-                    // a candidate out of the window ends the chain
-                    if (wmask != (take == 64 ? ~0ull : ((1ull << take) - 1ull))) done = true;
-                    left -= take;
-                    if (HAS_Q && !hq) {
-                        qleft -= take;
-                        if (qleft == 0 && !done) {  // lz77.rs:351-355 (the walk goes on: not the final result)
-                            mq = m_pack(bestd ? best : 0, bestd);
-                            hq = true;
-                        }
-                    }
-                    top -= (int32_t)take;
+                    for (uint32_t k = i; k < cnt; k++) dst[E + k] = lm[k];
                 }
             }
-            m = m_pack(bestd ? best : 0, bestd);
-        }
-        if (lane == 0) {
-            M[E + srel] = m;
-            if (HAS_Q) Mq[E + srel] = hq ? mq : m;
         }
     }
+#ifdef MI355_MATCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2631,21 +1495,6 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
     } else {
         for (uint32_t q = 0; q < 4 && r0 + q < left; q++) adv[t0 + r0 + q] = a[q];
     }
-}
-
-// k_adv_tail: the restart steps k_match3 left out -- the last ADV_HALO positions of every epoch that has a successor
-// (their steps look into the next epoch's table).  A workgroup per epoch boundary, the table read from global memory.
-struct GlobM {
-    const uint32_t* g;
-    __device__ uint32_t operator()(uint32_t p) const { return g[p]; }
-};
-__global__ __launch_bounds__(320) void k_adv_tail(uint32_t n, const uint32_t* __restrict__ M, ParseCfg cfg,
-                                                  uint16_t* __restrict__ adv, SegEnds sg) {
-    const uint64_t E1 = ((uint64_t)blockIdx.x + 1) * WINDOW_SIZE;  // the boundary: the first position of the next epoch
-    if (E1 >= n || threadIdx.x >= ADV_HALO) return;
-    const uint32_t p = (uint32_t)E1 - ADV_HALO + threadIdx.x;
-    const GlobM m{M};
-    adv[p] = (uint16_t)parse_step(m, m, p, rel_end(sg, 0, p), cfg).adv;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -552,457 +552,31 @@ MI355_HD void match_walk_park(const W& w, Next& next, const Lim& lim, uint32_t c
 #undef MI355_UNROLL
 }
 
-// ---- the same walk over hash-sorted positions (k_sort + k_match2) --------------------------------
-// Fourth formulation.  The positions of every 32 KiB epoch are sorted by (hash, position) -- S_e[0..J),
-// bucket h = S_e[B_e[h] .. B_e[h+1]) -- so the chain of matching.rs:124-132 for the entry j of bucket h
-// (position p) is S_e[j-1], S_e[j-2], ... down to B_e[h], then the bucket's entries of the previous
-// epoch from B_{e-1}[h+1]-1 downwards while they lie within 32768 of p: plain descending array reads
-// instead of a pointer chase, consecutive entries of a bucket (= consecutive lanes of a wave) read
-// consecutive addresses and have chains of nearly the same length.  A lane walks in RUNS: a run is a
-// stretch of one epoch's bucket cut to the budget left (max_hash_checks, and the quarter budget of
-// lz77.rs:351-355 while its result is still to be taken), so the common step only tests "index >= end
-// of run"; what is rare -- a probe hit (compare, matching.rs:141-156), the end of a run (take the
-// quarter result, go on in the previous epoch) -- parks the lane until the wave's next service.
-//
+// ---- the same walk over hash-sorted positions (k_sort + k_match3) --------------------------------
+// The positions of every 32 KiB epoch are sorted by (hash, position) -- S_e[0..J), bucket h =
+// S_e[B_e[h] .. B_e[h+1]) -- so the chain of matching.rs:124-132 for the entry j of bucket h (position p)
+// is S_e[j-1], S_e[j-2], ... down to B_e[h], then the bucket's entries of the previous epoch from
+// B_{e-1}[h+1]-1 downwards while they lie within 32768 of p: plain descending array reads instead of a
+// pointer chase, consecutive entries of a bucket (= consecutive lanes of a wave) read consecutive addresses
+// and have chains of nearly the same length.
 // Index space of `W::sidx(i)`: i < 32768 = entry i of the previous epoch's array, i >= 32768 = entry
-// i - 32768 of the own epoch's; values are positions relative to their epoch.  Byte coordinates
-// (`W::load32`): `org` = coordinate of the first byte of the previous epoch (of the own one for epoch
-// 0; an LDS address on the GPU, 0 on the host), `bias` = coordinate of the own epoch's first byte.
+// i - 32768 of the own epoch's; values are positions relative to their epoch.
+// (Two earlier formulations of this walk -- SortedLane: runs with a park state; SwLean: the predicated form
+// k_match2 ran over a byte image -- are in the history of this file.)
 enum : uint32_t { SW_OWN = 32768 };
-enum SwState : uint32_t { SW_WALK = 0, SW_PARK = 1, SW_RUNEND = 2, SW_DONE = 3 };
-
-template <bool HAS_Q>
-struct SortedLane {
-    uint32_t state;    // SwState
-    uint32_t prel;     // the searched position (byte coordinate)
-    uint32_t off;      // index of the candidate that is visited next (may wrap below 0 at the end of a run)
-    uint32_t endoff;   // last index of the current run
-    uint32_t c, nx;    // walking: sidx(off) and sidx(off - 1), read ahead
-    uint32_t bb;       // best_length - 1 + bias of the epoch the run is in: candidate value + bb = probe address
-    uint32_t lowa;     // probe addresses below this belong to candidates more than 32768 back (matching.rs:102-106)
-    uint32_t bm1;      // best_length - 1
-    uint32_t probe;    // bytes best-1, best of P (matching.rs:110,141)
-    uint32_t bestd;
-    uint32_t maxlen;   // matching.rs:112
-    uint32_t left;     // iterations left after the current run
-    uint32_t qleft;    // iterations left after the current run until the quarter result is taken
-    uint32_t range_lo; // lowest index of the bucket in the epoch the run is in
-    uint32_t pb0, pb1; // the bucket in the previous epoch: [pb0, pb1), empty when there is none
-    uint32_t low;      // prel - 32768 (coordinate 0 when that is negative): lowest candidate coordinate in reach
-    uint32_t mq;
-    uint32_t hq;       // quarter result taken
-    uint32_t acoord;   // probe address of the parked candidate
-    uint32_t in_prev;  // the run is in the previous epoch
-    uint32_t final;    // nothing can follow the current run
-    uint32_t p16[4];   // the first 16 bytes of P (sw_park_fast)
-};
-
-// start a run from `off` downwards; false = nothing left to visit in this epoch's bucket or no budget
-template <bool HAS_Q, class W>
-MI355_HD bool sw_start_run(SortedLane<HAS_Q>& s, const W& w) {
-    if ((int32_t)s.off < (int32_t)s.range_lo || s.left == 0) return false;
-    uint32_t r = s.off + 1 - s.range_lo;
-    if (r > s.left) r = s.left;
-    if (HAS_Q && !s.hq && r > s.qleft) r = s.qleft;
-    if (r == 0) return false;
-    s.endoff = s.off + 1 - r;
-    s.left -= r;
-    if (HAS_Q && !s.hq) s.qleft -= r;
-    s.c = w.sidx(s.off);
-    s.nx = w.sidx(s.off - 1);
-    s.state = SW_WALK;
-    // (a quarter result that falls due at the end of the last run equals the final result)
-    s.final = !(s.left > 0 && (s.endoff > s.range_lo || (!s.in_prev && s.pb1 > s.pb0)));
-    return true;
-}
-
-// Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the
-// previous epoch (pb0 == pb1 for epoch 0).  prel / nrel: position and end of the visible data, `org` =
-// coordinate of the first byte of the previous epoch (of the own one for epoch 0), `bias` = coordinate
-// of the own epoch's first byte.  checks_q = 0 with HAS_Q: the quarter budget is zero iterations, its
-// result empty.
-template <bool HAS_Q, class W>
-MI355_HD void sw_setup(SortedLane<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1,
-                       uint32_t prel, uint32_t nrel, uint32_t org, uint32_t bias, uint32_t checks, uint32_t checks_q) {
-    s.prel = prel;
-    s.low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
-    s.bm1 = 0;
-    s.bestd = 0;
-    s.mq = 0;
-    s.hq = 0;
-    s.pb0 = pb0;
-    s.pb1 = pb1;
-    s.in_prev = 0;
-    s.final = 0;
-    s.acoord = 0;
-    s.c = 0;
-    s.nx = 0;
-    s.endoff = 0;
-    s.left = checks;
-    s.qleft = checks_q;
-    if (HAS_Q && checks_q == 0) s.hq = 1;  // mq stays 0
-    s.range_lo = SW_OWN + own_b0;
-    s.off = SW_OWN + j - 1;
-    s.bb = bias;
-    s.lowa = s.low;
-    s.maxlen = 0;
-    s.probe = 0;
-    const bool search = prel + 2 < nrel && checks > 0;  // else no hash byte: never searched (lz77.rs:294-301)
-    if (!search) {
-        s.state = SW_DONE;
-        return;
-    }
-    const uint32_t left = nrel - prel;
-    s.maxlen = left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH;
-    w.load128(prel, s.p16);
-    s.probe = s.p16[0] & 0xffffu;
-    s.state = SW_RUNEND;  // the first service starts the first run (own epoch, else the previous one)
-}
-
-// One chain step of a walking lane: matching.rs:124-143 for the candidate at `off`.  (k_match2 runs
-// these steps as hand-scheduled code under the execution mask; the order of the tests is the same.)
-template <bool HAS_Q, class W>
-MI355_HD void sw_step(SortedLane<HAS_Q>& s, const W& w) {
-    const uint32_t a = s.c + s.bb;
-    const uint32_t rv = w.load32(a) & 0xffffu;
-    s.off -= 1;
-    s.acoord = a;
-    if (a < s.lowa) {  // more than 32768 back, and so is everything after it
-        s.state = SW_DONE;
-    } else if (rv == s.probe) {
-        s.state = SW_PARK;
-    } else if ((int32_t)s.off < (int32_t)s.endoff) {
-        s.state = s.final ? SW_DONE : SW_RUNEND;
-    } else {
-        s.c = s.nx;
-        s.nx = w.sidx(s.off - 1);
-    }
-}
-
-// The service as it runs on the GPU: straight-line for the common cases.  A parked lane: the candidate
-// against 16 bytes of P kept in registers (a loop only beyond those), matching.rs:148-156, then on to the
-// next candidate of the run.  A lane at the end
-// of its run in the own epoch with budget left and no quarter result pending: on to the bucket of the
-// previous epoch.  Only a lane that has to take the quarter result first keeps its state for sw_service.
-template <bool HAS_Q, class W>
-MI355_HD void sw_pending_fast(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
-    bool resume = false;
-    if (s.state == SW_PARK) {
-        const uint32_t c = s.acoord - s.bm1;
-        uint32_t q[4];
-        w.load128(c, q);
-        const uint64_t z0 = ((uint64_t)(q[1] ^ s.p16[1]) << 32) | (uint64_t)(q[0] ^ s.p16[0]);
-        const uint64_t z1 = ((uint64_t)(q[3] ^ s.p16[3]) << 32) | (uint64_t)(q[2] ^ s.p16[2]);
-        uint32_t len = z0 ? ((uint32_t)__builtin_ctzll(z0) >> 3) : (z1 ? 8u + ((uint32_t)__builtin_ctzll(z1) >> 3) : 16u);
-        if (len == 16) {  // the rare long match: eight more bytes per round
-            while (len < s.maxlen) {
-                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(c + len + 4)) << 32) |
-                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(c + len));
-                if (x) {
-                    len += (uint32_t)__builtin_ctzll(x) >> 3;
-                    break;
-                }
-                len += 8;
-            }
-        }
-        if (len > s.maxlen) len = s.maxlen;
-        if (len > s.bm1 + 1) {
-            const uint32_t ebias = s.bb - s.bm1;
-            s.bm1 = len - 1;
-            s.bestd = s.prel - c;
-            s.bb = s.bm1 + ebias;
-            s.lowa = s.low + s.bm1;
-            if (len == s.maxlen) {
-                s.state = SW_DONE;
-                return;
-            }
-            s.probe = w.load32(s.prel + s.bm1) & 0xffffu;
-        }
-        if ((int32_t)s.off >= (int32_t)s.endoff)
-            resume = true;
-        else
-            s.state = s.final ? SW_DONE : SW_RUNEND;
-    }
-    if (s.state == SW_RUNEND && (!HAS_Q || s.hq) && !s.in_prev && (int32_t)s.off < (int32_t)s.range_lo) {
-        // (not final: budget is left and the previous epoch's bucket has entries)
-        s.in_prev = 1;
-        s.range_lo = s.pb0;
-        s.off = s.pb1 - 1;
-        s.bb = s.bm1 + org;
-        uint32_t r = s.pb1 - s.pb0;
-        if (r > s.left) r = s.left;
-        s.endoff = s.off + 1 - r;
-        s.left -= r;
-        s.final = 1;
-        resume = true;
-    }
-    if (resume) {
-        s.c = w.sidx(s.off);
-        s.nx = w.sidx(s.off - 1);
-        s.state = SW_WALK;
-    }
-}
-
-// Service of a lane that is not walking: the compare of a parked candidate (matching.rs:148-156),
-// then the run bookkeeping.  Leaves the lane walking or done.
-template <bool HAS_Q, class W>
-MI355_HD void sw_service(SortedLane<HAS_Q>& s, const W& w, uint32_t org) {
-    if (s.state == SW_PARK) {
-        const uint32_t c = s.acoord - s.bm1;  // byte coordinate of the candidate
-        uint32_t len = 0;                     // get_match_length matching.rs:67-72, eight bytes per round
-        while (len < s.maxlen) {
-            const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(c + len + 4)) << 32) |
-                               (uint64_t)(w.load32(s.prel + len) ^ w.load32(c + len));
-            if (x) {
-                len += (uint32_t)__builtin_ctzll(x) >> 3;
-                break;
-            }
-            len += 8;
-        }
-        if (len > s.maxlen) len = s.maxlen;
-        if (len > s.bm1 + 1) {  // matching.rs:149-156
-            const uint32_t ebias = s.bb - s.bm1;  // bias of the epoch the run is in
-            s.bm1 = len - 1;
-            s.bestd = s.prel - c;
-            s.bb = s.bm1 + ebias;
-            s.lowa = s.low + s.bm1;
-            if (len == s.maxlen) {
-                s.state = SW_DONE;
-                return;
-            }
-            s.probe = w.load32(s.prel + s.bm1) & 0xffffu;
-        }
-        if ((int32_t)s.off >= (int32_t)s.endoff) {
-            s.c = w.sidx(s.off);
-            s.nx = w.sidx(s.off - 1);
-            s.state = SW_WALK;
-            return;
-        }
-        s.state = s.final ? SW_DONE : SW_RUNEND;
-    }
-    if (s.state == SW_RUNEND) {
-        if (HAS_Q && !s.hq && s.qleft == 0) {  // lz77.rs:351-355: the state after max_hash_checks >> 2 iterations
-            s.mq = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
-            s.hq = 1;
-        }
-        if (sw_start_run(s, w)) return;
-        if (!s.in_prev && s.left > 0 && s.pb1 > s.pb0) {  // go on in the previous epoch's bucket
-            s.in_prev = 1;
-            s.range_lo = s.pb0;
-            s.off = s.pb1 - 1;
-            s.bb = s.bm1 + org;  // the previous epoch's values count from the origin
-            if (sw_start_run(s, w)) return;
-        }
-        s.state = SW_DONE;
-    }
-}
-
-template <bool HAS_Q>
-MI355_HD void sw_result(const SortedLane<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
-    const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
-    *m = r;
-    *mq = (HAS_Q && s.hq) ? s.mq : r;
-}
-
-// ---- the sorted walk as the GPU runs it (k_match2): predicated, one service per block of steps ---------
-// Same lists, same runs and the same tests as SortedLane above, reshaped for a wave: per-lane flags are
-// lane masks (lane_flag), the step block (swl_steps_ref here, hand-scheduled code under the execution
-// mask on the GPU) takes R steps for the walking lanes, and ONE straight-line service then settles every
-// lane that dropped out of the block -- compare, result update, end of run, move to the previous epoch's
-// bucket -- by selects, so that a lane is either walking or done between blocks.  Indices are kept as byte
-// offsets: offb = 2 * index + 8 (the form the GPU's loads want), lob / lob2 = offset of the first entry of
-// the bucket in the own / previous epoch's part, offb2 = offset of the previous epoch's last bucket entry.
-template <bool HAS_Q>
-struct SwLean {
-    uint32_t offb, endb, c, nx, a, rv, bb, lowa, probe;  // the registers of the step block
-    uint32_t bm1, bestd, prel, maxlen, low, p16[4];
-    uint32_t lob, offb2, lob2, left, qleft, mq;
-    lane_flag walk, done, in_prev, final, hq;
-};
-
 MI355_HD lane_flag lf_and_not(lane_flag a, lane_flag b) { return a & lf_not(b); }
 
-// R chain steps of a walking lane (host twin of the GPU's step block; the order of the tests is the GPU's):
-// window, probe, end of run.  A lane that drops out keeps a / rv of its last candidate; offb already
-// points at the entry after it.
-template <bool HAS_Q, class W>
-MI355_HD void swl_steps_ref(SwLean<HAS_Q>& s, const W& w, uint32_t R) {
-    if (!lf_me(s.walk)) return;
-    s.c = w.sidx((uint32_t)((int32_t)(s.offb - 8) >> 1));
-    s.nx = w.sidx((uint32_t)((int32_t)(s.offb - 10) >> 1));
-    for (uint32_t k = 0; k < R; k++) {
-        s.a = s.c + s.bb;
-        s.rv = w.load32(s.a) & 0xffffu;
-        s.offb -= 2;
-        if (s.a < s.lowa || s.rv == s.probe || (int32_t)s.offb < (int32_t)s.endb) {
-            s.walk = lf_of(false);
-            return;
-        }
-        s.c = s.nx;
-        s.nx = w.sidx((uint32_t)((int32_t)(s.offb - 10) >> 1));
-    }
-}
-
-// Settle the lanes that left the last block (`dropped`) and the lanes that have not started yet (`start`:
-// their first run begins).  Straight-line selects; only a match longer than 16 bytes loops.
-template <bool HAS_Q, class W>
-MI355_HD void swl_service(SwLean<HAS_Q>& s, const W& w, uint32_t org, lane_flag dropped, lane_flag start) {
-    const lane_flag out = dropped & lf_of(s.a < s.lowa);                      // matching.rs:102-106,127
-    const lane_flag hit = lf_and_not(dropped, out) & lf_of(s.rv == s.probe);  // matching.rs:141-143
-    lane_flag rend = lf_and_not(lf_and_not(dropped, out), hit) | start;
-    // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
-    const uint32_t cpos = s.a - s.bm1;
-    uint32_t q[4];
-    w.load128(cpos, q);
-    // first differing bit of the 128: ffs - 1 is all ones for a zero word, which the OR keeps largest
-    const uint32_t b0 = (uint32_t)(__builtin_ffs((int)(q[0] ^ s.p16[0])) - 1);
-    const uint32_t b1 = (uint32_t)(__builtin_ffs((int)(q[1] ^ s.p16[1])) - 1) | 32u;
-    const uint32_t b2 = (uint32_t)(__builtin_ffs((int)(q[2] ^ s.p16[2])) - 1) | 64u;
-    const uint32_t b3 = (uint32_t)(__builtin_ffs((int)(q[3] ^ s.p16[3])) - 1) | 96u;
-    uint32_t bits = b0 < b1 ? b0 : b1;
-    const uint32_t bh = b2 < b3 ? b2 : b3;
-    bits = bits < bh ? bits : bh;
-    uint32_t len = (bits < 128u ? bits : 128u) >> 3;
-    const lane_flag lng = hit & lf_of(len == 16 && s.maxlen > 16);
-    if (lf_any(lng)) {
-        if (lf_me(lng)) {
-            while (len < s.maxlen) {
-                const uint64_t x = ((uint64_t)(w.load32(s.prel + len + 4) ^ w.load32(cpos + len + 4)) << 32) |
-                                   (uint64_t)(w.load32(s.prel + len) ^ w.load32(cpos + len));
-                if (x) {
-                    len += (uint32_t)__builtin_ctzll(x) >> 3;
-                    break;
-                }
-                len += 8;
-            }
-        }
-    }
-    len = len < s.maxlen ? len : s.maxlen;
-    const lane_flag imp = hit & lf_of(len > s.bm1 + 1);  // matching.rs:149-156
-    const uint32_t delta = lf_me(imp) ? len - 1 - s.bm1 : 0u;
-    s.bestd = lf_me(imp) ? s.prel - cpos : s.bestd;
-    s.bm1 += delta;
-    s.bb += delta;
-    s.lowa += delta;
-    const lane_flag full = imp & lf_of(len == s.maxlen);
-    const uint32_t pr = w.load32(s.prel + s.bm1) & 0xffffu;
-    s.probe = lf_me(imp) ? pr : s.probe;
-    const lane_flag more = lf_of((int32_t)s.offb >= (int32_t)s.endb);
-    const lane_flag hgo = lf_and_not(hit, full);
-    rend = rend | lf_and_not(hgo, more);
-    const lane_flag resume = hgo & more;
-    s.done = s.done | out | full | (lf_and_not(rend, start) & s.final);
-    rend = lf_and_not(rend, lf_and_not(s.final, start));
-    // end of a run that is not the last one (sw_service above): the quarter result, then the rest of the
-    // bucket, else the bucket of the previous epoch
-    if (HAS_Q) {
-        const lane_flag cap = lf_and_not(rend, s.hq) & lf_of(s.qleft == 0);  // lz77.rs:351-355
-        s.mq = lf_me(cap) ? m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd) : s.mq;
-        s.hq = s.hq | cap;
-    }
-    const int32_t av1 = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
-    const lane_flag same = rend & lf_of(av1 > 0 && s.left > 0);
-    const lane_flag sw =
-        lf_and_not(lf_and_not(rend, same), s.in_prev) & lf_of(s.left > 0 && (int32_t)s.offb2 >= (int32_t)s.lob2);
-    s.done = s.done | lf_and_not(lf_and_not(rend, same), sw);
-    s.offb = lf_me(sw) ? s.offb2 : s.offb;
-    s.lob = lf_me(sw) ? s.lob2 : s.lob;
-    s.bb = lf_me(sw) ? s.bm1 + org : s.bb;
-    s.in_prev = s.in_prev | sw;
-    const lane_flag go = same | sw;
-    const int32_t av = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
-    uint32_t r = (uint32_t)av < s.left ? (uint32_t)av : s.left;
-    if (HAS_Q) r = (lf_me(s.hq) || r < s.qleft) ? r : s.qleft;
-    r = lf_me(go) ? r : 0u;
-    s.endb = lf_me(go) ? s.offb + 2 - 2 * r : s.endb;
-    s.left -= r;
-    if (HAS_Q) s.qleft -= lf_me(s.hq) ? 0u : r;
-    const lane_flag fin = lf_of(!(s.left > 0 && ((int32_t)s.endb > (int32_t)s.lob ||
-                                                 (!lf_me(s.in_prev) && (int32_t)s.offb2 >= (int32_t)s.lob2))));
-    s.final = lf_and_not(s.final, go) | (go & fin);
-    s.walk = lf_and_not(s.walk | resume | go, s.done);
-}
-
-// The first run of the lanes in `start` (the run part of swl_service alone: a lane that has not walked yet
-// has nothing to compare).
-template <bool HAS_Q>
-MI355_HD void swl_start(SwLean<HAS_Q>& s, uint32_t org, lane_flag start) {
-    const int32_t av1 = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
-    const lane_flag same = start & lf_of(av1 > 0 && s.left > 0);
-    const lane_flag sw = lf_and_not(start, same) & lf_of(s.left > 0 && (int32_t)s.offb2 >= (int32_t)s.lob2);
-    s.done = s.done | lf_and_not(lf_and_not(start, same), sw);
-    s.offb = lf_me(sw) ? s.offb2 : s.offb;
-    s.lob = lf_me(sw) ? s.lob2 : s.lob;
-    s.bb = lf_me(sw) ? s.bm1 + org : s.bb;
-    s.in_prev = s.in_prev | sw;
-    const lane_flag go = same | sw;
-    const int32_t av = (((int32_t)s.offb - (int32_t)s.lob) >> 1) + 1;
-    uint32_t r = (uint32_t)av < s.left ? (uint32_t)av : s.left;
-    if (HAS_Q) r = (lf_me(s.hq) || r < s.qleft) ? r : s.qleft;
-    r = lf_me(go) ? r : 0u;
-    s.endb = lf_me(go) ? s.offb + 2 - 2 * r : s.endb;
-    s.left -= r;
-    if (HAS_Q) s.qleft -= lf_me(s.hq) ? 0u : r;
-    const lane_flag fin = lf_of(!(s.left > 0 && ((int32_t)s.endb > (int32_t)s.lob ||
-                                                 (!lf_me(s.in_prev) && (int32_t)s.offb2 >= (int32_t)s.lob2))));
-    s.final = lf_and_not(s.final, go) | (go & fin);
-    s.walk = lf_and_not(go, s.done);
-}
-
-// Set a lane up for entry j of its epoch's array (see sw_setup); the first service call starts its run.
-// Returns whether the position is searched at all.
-template <bool HAS_Q, class W>
-MI355_HD bool swl_setup(SwLean<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, uint32_t pb0, uint32_t pb1, uint32_t prel,
-                        uint32_t nrel, uint32_t org, uint32_t bias, uint32_t checks, uint32_t checks_q) {
-    s.prel = prel;
-    s.low = prel - org > (uint32_t)WINDOW_SIZE ? prel - (uint32_t)WINDOW_SIZE : org;
-    s.bm1 = 0;
-    s.bestd = 0;
-    s.mq = 0;
-    s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
-    s.in_prev = lf_of(false);
-    s.final = lf_of(false);
-    s.done = lf_of(false);
-    s.walk = lf_of(false);
-    s.a = org;
-    s.rv = 0;
-    s.c = 0;
-    s.nx = 0;
-    s.left = checks;
-    s.qleft = checks_q;
-    s.lob = 2 * (SW_OWN + own_b0) + 8;
-    s.offb = 2 * (SW_OWN + j - 1) + 8;
-    s.endb = s.offb + 2;  // (no run yet)
-    s.offb2 = 2 * (pb1 - 1) + 8;
-    s.lob2 = 2 * pb0 + 8;
-    s.bb = bias;
-    s.lowa = s.low;
-    const bool search = prel + 2 < nrel && checks > 0;  // else no hash byte: never searched (lz77.rs:294-301)
-    const uint32_t left = nrel - prel;
-    s.maxlen = search ? (left < (uint32_t)MAX_MATCH ? left : (uint32_t)MAX_MATCH) : 0u;
-    w.load128(prel, s.p16);
-    s.probe = s.p16[0] & 0xffffu;
-    return search;
-}
-
-template <bool HAS_Q>
-MI355_HD void swl_result(const SwLean<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
-    const uint32_t r = m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd);
-    *m = r;
-    *mq = (HAS_Q && lf_me(s.hq)) ? s.mq : r;
-}
-
-// ---- the sorted walk, third form (k_match3): pair table, probes four at a time -------------------------
+// ---- the sorted walk as the GPU runs it (k_match3): pair table, probes eight at a time -------------------------
 // What longest_match computes for prev_length = 0 is a pure function of the candidate list: among the first
 // K candidates of the chain that lie within 32768 bytes (matching.rs:119-132), the one with the longest
 // common prefix with P, the nearest among equals, if that prefix is at least 2 bytes (matching.rs:149-156
 // only ever replaces the best by a strictly longer one).  The two-byte probe at best-1, best
 // (matching.rs:141-143) never rejects a candidate that would improve the result, so ANY test that passes
 // every candidate the probe passes gives the same answer: a candidate looked at in vain is compared and
-// dropped.  k_match3 uses that freedom in one place only -- it reads the probe bytes of FOUR consecutive
-// candidates before it looks at the first answer, so a lane that finds a hit has asked about up to three
-// candidates it does not need yet (and, at the end of a run, about up to three entries beyond it, which the
-// service discards by index).  Everything else is the walk of SwLean above, with these changes:
+// dropped.  k_match3 uses that freedom in one place only -- it reads the probe bytes of EIGHT consecutive
+// candidates before it looks at the first answer, so a lane that finds a hit has asked about up to seven
+// candidates it does not need yet (and, at the end of a run, about up to seven entries beyond it, which the
+// service discards by index).  How the walk is laid out:
 //   * the window's bytes sit in LDS as a table of PAIRS, T[k] = byte k | byte k+1 << 8: the probe is one
 //     aligned two-byte read at any k (the byte image needed two one-byte reads and a shift per candidate),
 //     and the sorted arrays hold 2 * position, so that entry + bb2 IS the address of the probe;
@@ -1013,12 +587,6 @@ MI355_HD void swl_result(const SwLean<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
 //     settled (or the final result, when there is none): no run ends there.
 // Coordinates: positions count from the window's first byte (`org` = 0); probe addresses are LDS addresses
 // tbase + (position << W::SH) (tbase = 0 on the host), and the sorted arrays hold position << W::SH.
-// The table need not even hold the pair itself: W::key_at may return any function of the two bytes (k_match4
-// keeps an 8-bit hash of every pair, one byte per position, and fetches the bytes of a compare from global
-// memory) -- two positions whose pairs are equal have equal keys, so no candidate the probe would pass is
-// lost, and one passed in vain is compared and dropped like any other.
-// k_match4's key of a byte pair (any function of the two bytes would do; this one keeps letters apart)
-MI355_HD uint32_t pair_key8(uint32_t x, uint32_t y) { return (x ^ (y << 3) ^ (y >> 5)) & 0xffu; }
 
 template <bool HAS_Q>
 struct SwG {
@@ -1121,10 +689,10 @@ MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d, uint32_t width) {
 // probe's address, `ho` = the offset of its entry (the caller picks them from a / t and offb: which step it was
 // is read off the probe bytes; the others left at the end of their group).  Straight-line selects; only a match
 // longer than 16 bytes loops.
-// (qgiven: the candidate's sixteen bytes are handed in -- k_match3's first service takes them from the neighbouring lane)
-template <bool HAS_Q, class W>
+// RUN1: the variant for inputs made of long runs of one byte (see the long compare below); chosen per launch.
+template <bool RUN1, bool HAS_Q, class W>
 MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
-                          uint32_t asel, uint32_t ho, const uint32_t* qgiven = nullptr) {
+                          uint32_t asel, uint32_t ho) {
     // a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of the window
     // (positions fall along a segment, so the hit's own address tells), is no hit
     // (one comparison per ballot: a ballot of `a && b` makes the compiler turn a lane mask into 0 / 1 values and back)
@@ -1133,14 +701,7 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
     const uint32_t cpos = ((asel - tbase) >> W::SH) - s.bm1;
     uint32_t q[4];
-    if (qgiven) {
-        q[0] = qgiven[0];
-        q[1] = qgiven[1];
-        q[2] = qgiven[2];
-        q[3] = qgiven[3];
-    } else {
-        w.load16(cpos, q);
-    }
+    w.load16(cpos, q);
     const uint32_t b0 = first_bit_or_ones(q[0] ^ s.p16[0]);
     const uint32_t b1 = first_bit_or_ones(q[1] ^ s.p16[1]) | 32u;
     const uint32_t b2 = first_bit_or_ones(q[2] ^ s.p16[2]) | 64u;
@@ -1155,10 +716,9 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
         // (data[c + k] == data[c + k + 1] for every k below the length): when that is so for every lane that goes on --
         // a run of one byte, where each position's first candidate is its neighbour -- the rounds read the position's
         // side only and compare it with that byte four times over (zero fill at Default was all this loop).
-        // (-DMI355_RUN1_COMPARE; measured: zero fill at Default 30.5 -> 35.9 GB/s, but the text loses 1 % -- 3.63 -> 3.67 ms --
-        // to the longer service: off)
-#ifdef MI355_RUN1_COMPARE
-        if (!lf_any(lng & lf_of(s.prel - cpos != 1u))) {
+        // (RUN1; measured: zero fill at Default 30.5 -> 35.9 GB/s, but the text loses 1 % -- 3.63 -> 3.67 ms -- to the longer
+        // service, so it is an instantiation of its own that the host picks for inputs of that kind)
+        if (RUN1 && !lf_any(lng & lf_of(s.prel - cpos != 1u))) {
             if (lf_me(lng)) {
                 const uint32_t b4 = (q[0] & 0xffu) * 0x01010101u;
                 while (len < s.maxlen) {
@@ -1178,9 +738,7 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
                     len += 16;
                 }
             }
-        } else
-#endif
-        if (lf_me(lng)) {  // sixteen more bytes per round (runs of one byte take sixteen rounds to 258)
+        } else if (lf_me(lng)) {  // sixteen more bytes per round (runs of one byte take sixteen rounds to 258)
             while (len < s.maxlen) {
                 uint32_t pa[4], ca[4];
                 w.load16(s.prel + len, pa);

@@ -168,6 +168,9 @@ def load():
     L.mi355_checksum_combine.restype = C.c_uint32
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
+    L.mi355_deflate_ctx_config.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    L.mi355_deflate_stream_held_bytes.argtypes = [C.c_void_p]
+    L.mi355_deflate_stream_held_bytes.restype = C.c_uint64
     L.mi355_deflate_stream_free.restype = None
     _lib = L
     return L
@@ -187,6 +190,7 @@ EXPORTED = [
     "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_shard_blocks_ex",
     "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
+    "mi355_deflate_ctx_config", "mi355_deflate_stream_held_bytes",
 ]
 
 
@@ -216,6 +220,14 @@ class Context:
 
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
+
+    CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS = 1, 2, 3
+
+    def config(self, key, value):
+        """mi355_deflate_ctx_config: range size / long-input threshold / where the sort takes its ranks from"""
+        rc = load().mi355_deflate_ctx_config(self._h, int(key), int(value))
+        if rc != OK:
+            raise DeflateError(rc, self.last_error())
 
     def reserve(self, in_len, host_api=False):
         """mi355_deflate_ctx_reserve: allocate for inputs of up to in_len bytes now"""

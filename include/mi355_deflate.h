@@ -34,7 +34,7 @@ extern "C" {
                                       written since the last flush() of a stream that has been flushed before */
 #define MI355_E_REF_PANIC (-5)     /* the reference itself panics on this input (A.4 Q13, slice out
                                       of range) and MI355_COMPAT_Q13 was requested */
-#define MI355_E_STATE (-6)         /* stream used after finish */
+#define MI355_E_STATE (-6)         /* stream used after finish, or after a range of it failed; context busy with a shard */
 
 /* CompressionOptions (src/compression_options.rs:78-120) + MatchingType (src/lz77.rs:27-37).
  * `special` has only the Normal variant reachable from the public API and is omitted. */
@@ -97,16 +97,36 @@ size_t mi355_deflate_bound_ex(size_t in_len, int wrapper, size_t hdr_len, size_t
  * from several threads are safe (and serialised).
  * Creating a context runs one short self-test kernel on the device (about 0.1 ms): the hash sort takes its ranks
  * from returning LDS atomics when -- and only when -- the device serves the lanes that hit one LDS address in lane
- * order (MI355X does); otherwise it ranks with ballots.  The output is the same either way. */
+ * order (MI355X does); otherwise it ranks with ballots.  The output is the same either way, and every encode
+ * checks the order of the sorted buckets it walks (MI355_CFG_SORT_RANKS below).
+ * A context that holds a sharded encode (between mi355_shard_begin and mi355_shard_end) refuses other encodes
+ * with MI355_E_STATE: the shard's tokens and tables live in the context's workspace. */
 typedef struct mi355_deflate_ctx mi355_deflate_ctx;
 int mi355_deflate_ctx_create(int device, mi355_deflate_ctx** out);
 void mi355_deflate_ctx_destroy(mi355_deflate_ctx* ctx);
 const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 
+/* Tuning of one context (ctx may be NULL: the default context).  No reference item: the reference has no tunables
+ * beyond CompressionOptions; these set the memory / throughput trade of the GPU path, never the bytes it produces.
+ *   MI355_CFG_RANGE_BYTES  bytes per range of a long input or never-flushed stream (default 512 MiB; at least 16 MiB,
+ *                          at most 3 GiB, rounded down to a multiple of 32768).  Device memory of a long encode is two
+ *                          workspaces of about 20 B per byte of a range, host memory of a stream one range + 16 MiB.
+ *   MI355_CFG_LONG_FROM    one-shot inputs of at least this many bytes are walked in ranges (default 1 GiB + 1; at most
+ *                          4 GiB - 64 KiB, what a single pass takes)
+ *   MI355_CFG_SORT_RANKS   where the hash sort takes its ranks from: 1 = returning LDS atomics (the default on a device
+ *                          that passed the self-test of mi355_deflate_ctx_create; MI355_E_UNSUPPORTED on one that did
+ *                          not), 0 = ballots (any device; about 40 % more time in the sort).  Whatever the setting, the
+ *                          match kernel checks every hash bucket's order on the data it walks and an encode that finds
+ *                          one out of order is done again with ballot ranks, which the context then keeps. */
+#define MI355_CFG_RANGE_BYTES 1
+#define MI355_CFG_LONG_FROM 2
+#define MI355_CFG_SORT_RANKS 3
+int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
+
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
  * in, host buffer out.  ctx may be NULL (the default context, see above).  An input of 16 MiB or more is
- * copied in two pieces and worked on while the second is still on the bus; that only overlaps when `in` is
- * page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap.
+ * copied in up to four pieces and worked on while the later ones are still on the bus; that only overlaps when `in`
+ * is page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap.
  * Any in_len is taken, like src/lib.rs:137-147: an input of more than 1 GiB is walked as consecutive ranges of
  * 512 MiB (csrc/deflate_long.inc -- the phases of the sharded encode below, one range after the other on this
  * GPU; the same bytes as a single pass), which also bounds the device memory of a call: two workspaces of
@@ -279,7 +299,18 @@ int mi355_deflate_stream_reset(mi355_deflate_stream* s, const uint8_t** data, si
 int mi355_deflate_stream_output(mi355_deflate_stream* s, const uint8_t** data, size_t* n);
 int mi355_deflate_stream_take_output(mi355_deflate_stream* s, uint8_t* dst, size_t cap, size_t* n);
 int mi355_deflate_stream_checksum(mi355_deflate_stream* s, uint32_t* adler);
+/* Host memory the handle holds right now: gathered input, the window, bytes produced and not yet taken (what the
+ * reference bounds at about 330 KiB, src/deflate_state.rs:82-119; here one range for a stream that is never flushed). */
+uint64_t mi355_deflate_stream_held_bytes(mi355_deflate_stream* s);
 void mi355_deflate_stream_free(mi355_deflate_stream* s);
+
+#ifdef MI355_DEBUG_HOOKS
+/* Test build only (libmi355deflate_dbg.so, `make debug`; never part of the product library): make the hash sort of this
+ * context hand out a wrong order, as a device would whose LDS did not serve same-address lanes in lane order, so that
+ * a test can watch the match kernel's order check catch it.  _sort_ranks reports what the context sorts with now. */
+int mi355_debug_break_sort(mi355_deflate_ctx* ctx, int on);
+int mi355_debug_sort_ranks(mi355_deflate_ctx* ctx);
+#endif
 
 #ifdef __cplusplus
 }

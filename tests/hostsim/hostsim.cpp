@@ -81,9 +81,9 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
-    if (g_multi == 4 || g_multi == 5 || g_multi == 6) {
-        // the k_sort + k_match2 formulation: epochs sorted by (hash, position), lanes walk runs of the
-        // sorted arrays (stages.h SortedLane); step / service alternate as on the GPU
+    if (g_multi == 6 || g_multi == 7) {
+        // the k_sort + k_match3 formulation: epochs sorted by (hash, position), lanes walk their bucket's
+        // entries (stages.h SwG); groups of steps and services alternate as on the GPU (7: the RUN1 service)
         const uint32_t W = WINDOW_SIZE;
         HostBytes by{s.in.data()};
         bool hasq = s.cfg.use_quarter && cq != 0;
@@ -105,25 +105,8 @@ void stage_match(Sim& s) {
             for (uint32_t r : order) curB[hh[r] + 1]++;
             for (uint32_t h = 0; h < 32768; h++) curB[h + 1] += curB[h];
             curS.assign(order.begin(), order.end());
-            struct Win {
-                const uint8_t* d;      // byte coordinate 0
-                const uint16_t* ps;    // previous epoch's array
-                const uint16_t* cs;    // own
-                uint32_t load32(uint32_t i) const {
-                    uint32_t v;
-                    memcpy(&v, d + i, 4);
-                    return v;
-                }
-                void load128(uint32_t i, uint32_t* q) const { memcpy(q, d + i, 16); }
-                uint32_t np, nc;       // entries in the two arrays (reads ahead of a run's end may fall outside)
-                uint32_t sidx(uint32_t i) const {
-                    if (i >= SW_OWN) return i - SW_OWN < nc ? cs[i - SW_OWN] : 0u;
-                    return i < np ? ps[i] : 0u;
-                }
-            };
             const uint64_t wbase = E >= W ? E - W : 0;
             const uint32_t bias = (uint32_t)(E - wbase);
-            Win win{s.in.data() + wbase, prevS.data(), curS.data(), (uint32_t)prevS.size(), (uint32_t)curS.size()};
             for (uint32_t j = 0; j < curS.size(); j++) {
                 const uint32_t r = curS[j], h = hh[r];
                 const uint32_t prel = bias + r, nrel = (uint32_t)(s.n - wbase);
@@ -133,34 +116,6 @@ void stage_match(Sim& s) {
                     pb1 = prevB[h + 1];
                 }
                 uint32_t m = 0, mq = 0;
-                auto run = [&](auto& ln) {
-                    sw_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
-                    uint32_t guard = 0;
-                    while (ln.state != SW_DONE) {
-                        for (int k = 0; k < 5; k++)
-                            if (ln.state == SW_WALK) sw_step(ln, win);
-                        if (ln.state != SW_WALK && ln.state != SW_DONE && (guard & 1))
-                            sw_pending_fast(ln, win, 0u);  // (every other time: both paths run)
-                        if (ln.state != SW_WALK && ln.state != SW_DONE) sw_service(ln, win, 0u);
-                        if (++guard > 100000) break;
-                    }
-                    sw_result(ln, &m, &mq);
-                };
-                auto run5 = [&](auto& ln) {  // the predicated form k_match2 runs: block of steps, one service
-                    const bool search = swl_setup(ln, win, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
-                    ln.done = lf_of(!search);
-                    if (j & 1)  // (both ways of starting a lane)
-                        swl_service(ln, win, 0u, lf_of(false), lf_of(search));
-                    else
-                        swl_start(ln, 0u, lf_of(search));
-                    uint32_t guard = 0;
-                    while (lf_me(ln.walk)) {
-                        swl_steps_ref(ln, win, 3 + (guard % 4) * 3);
-                        swl_service(ln, win, 0u, lf_not(ln.walk), lf_of(false));
-                        if (++guard > 100000) break;
-                    }
-                    swl_result(ln, &m, &mq);
-                };
                 // the k_match3 form: pair table, groups of four probes, the service decodes where a lane stopped
                 struct PWin {  // pair table: the key is the pair, entries and addresses count two bytes per position
                     enum : uint32_t { SH = 1 };
@@ -180,14 +135,6 @@ void stage_match(Sim& s) {
                         return i < np ? 2u * ps[i] : 0u;
                     }
                 };
-                struct HWin : PWin {  // k_match4: one byte per position, an 8-bit hash of the pair
-                    enum : uint32_t { SH = 0 };
-                    uint32_t key_at(uint32_t a) const { return pair_key8(byte(a), byte(a + 1)); }
-                    uint32_t sidx(uint32_t i) const {
-                        if (i >= SW_OWN) return i - SW_OWN < nc ? (uint32_t)cs[i - SW_OWN] : 0u;
-                        return i < np ? (uint32_t)ps[i] : 0u;
-                    }
-                };
                 auto run6 = [&](auto& ln, auto pw) {
                     pw.d = s.in.data() + wbase;
                     pw.nb = (uint64_t)s.in.size() - wbase;
@@ -204,7 +151,10 @@ void stage_match(Sim& s) {
                     for (;;) {
                         if (lf_me(dropped)) {
                             const uint32_t av[8] = {ln.a0, ln.a1, ln.a2, ln.a3, ln.a4, ln.a5, ln.a6, ln.a7};
-                            swg_service(ln, pw, 0u, cq, dropped, lf_of(d >= 0), d >= 0 ? av[d] : 0u, ln.offb + 2 * (width - (d >= 0 ? d : 0)));
+                            if (g_multi == 7)
+                                swg_service<true>(ln, pw, 0u, cq, dropped, lf_of(d >= 0), d >= 0 ? av[d] : 0u, ln.offb + 2 * (width - (d >= 0 ? d : 0)));
+                            else
+                                swg_service<false>(ln, pw, 0u, cq, dropped, lf_of(d >= 0), d >= 0 ? av[d] : 0u, ln.offb + 2 * (width - (d >= 0 ? d : 0)));
                         }
                         if (!lf_me(ln.walk)) break;
                         const uint32_t groups = 1 + (guard % 3);
@@ -215,35 +165,12 @@ void stage_match(Sim& s) {
                     }
                     swg_result(ln, &m, &mq);
                 };
-                if (g_multi == 6) {
-                    // (the pair table of k_match3 and the pair-hash table of k_match4, turn and turn about)
-                    if (hasq) {
-                        SwG<true> ln;
-                        if (j & 8)
-                            run6(ln, HWin());
-                        else
-                            run6(ln, PWin());
-                    } else {
-                        SwG<false> ln;
-                        if (j & 8)
-                            run6(ln, HWin());
-                        else
-                            run6(ln, PWin());
-                    }
-                } else if (g_multi == 5) {
-                    if (hasq) {
-                        SwLean<true> ln;
-                        run5(ln);
-                    } else {
-                        SwLean<false> ln;
-                        run5(ln);
-                    }
-                } else if (hasq) {
-                    SortedLane<true> ln;
-                    run(ln);
+                if (hasq) {
+                    SwG<true> ln;
+                    run6(ln, PWin());
                 } else {
-                    SortedLane<false> ln;
-                    run(ln);
+                    SwG<false> ln;
+                    run6(ln, PWin());
                 }
                 s.M[E + r] = m;
                 s.Mq[E + r] = mq;

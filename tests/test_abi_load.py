@@ -18,11 +18,20 @@ def test_header_symbols_are_exported():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "deflate-rs_amd"), "-s"])
     L = deflate_amd.load()
     hdr = open(os.path.join(ROOT, "include", "mi355_deflate.h")).read()
-    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    # (the hooks under MI355_DEBUG_HOOKS belong to the test build libmi355deflate_dbg.so only)
+    product_hdr, n_dbg = re.subn(r"#ifdef MI355_DEBUG_HOOKS.*?#endif", "", hdr, flags=re.S)
+    assert n_dbg == 1
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", product_hdr))
     assert len(declared) >= 17
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(deflate_amd.EXPORTED)
+    # ... and nothing else: every mi355_* symbol the product library exports is declared in the header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", deflate_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b[TDB] (mi355_[a-z0-9_]+)$", nm, flags=re.M))
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert not any(x.startswith("mi355_debug") for x in exported)
     assert L.mi355_deflate_version() >= 100
     assert L.mi355_deflate_bound(0) >= 16
 

@@ -689,17 +689,17 @@ def test_long_stream_keeps_only_its_window(da, ctx, level):
 
 
 # ---- SURVEY section 8 row g: inputs of any length, never-flushed streams in bounded memory (deflate_long.inc) ----
-def _set_long(da, range_bytes, from_bytes):
-    da.load().mi355_debug_set_long.argtypes = [C.c_uint64, C.c_uint64]
-    da.load().mi355_debug_set_long(range_bytes, from_bytes)
+def _set_long(ctx, range_bytes, from_bytes):
+    ctx.config(ctx.CFG_RANGE_BYTES, range_bytes)
+    ctx.config(ctx.CFG_LONG_FROM, from_bytes)
 
 
 @pytest.fixture
-def small_ranges(da):
-    """16 MiB ranges, every one-shot call of 20 MB or more goes through them"""
-    _set_long(da, 16 << 20, 20_000_000)
+def small_ranges(da, ctx):
+    """16 MiB ranges, every one-shot call of 20 MB or more goes through them (mi355_deflate_ctx_config)"""
+    _set_long(ctx, 16 << 20, 20_000_000)
     yield
-    _set_long(da, 512 << 20, (1 << 30) + 1)
+    _set_long(ctx, 512 << 20, (1 << 30) + 1)
 
 
 def test_long_input_walked_in_ranges(da, ctx, small_ranges):
@@ -739,8 +739,6 @@ def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
     import random
     data = datagen.text_like(70_000_000, 91)
     L = da.load()
-    L.mi355_debug_stream_held.restype = C.c_uint64
-    L.mi355_debug_stream_held.argtypes = [C.c_void_p]
     for wrapper, cls, lv in ((0, da.DeflateEncoder, "default"), (1, da.ZlibEncoder, "default"), (2, da.GzEncoder, "fast")):
         c, l, m = LV[lv]
         for flush_at in (None, 45_000_000):
@@ -757,7 +755,7 @@ def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
                 enc.write_all(data[pos:pos + step])
                 ref.write_all(data[pos:pos + step])
                 pos += step
-                held = max(held, L.mi355_debug_stream_held(enc._s))
+                held = max(held, L.mi355_deflate_stream_held_bytes(enc._s))
                 if flush_at and pos == flush_at:
                     enc.flush()
                     ref.flush()
@@ -779,10 +777,8 @@ def test_stream_beyond_4gib_without_flush(da, ctx):
     import io
     block = datagen.webtext(64 << 20)
     reps = 68
-    _set_long(da, 512 << 20, (1 << 30) + 1)
+    _set_long(ctx, 512 << 20, (1 << 30) + 1)
     L = da.load()
-    L.mi355_debug_stream_held.restype = C.c_uint64
-    L.mi355_debug_stream_held.argtypes = [C.c_void_p]
 
     class Check:  # the inner writer: inflates what it is given and compares it with the input, keeps nothing
         def __init__(self):
@@ -806,7 +802,7 @@ def test_stream_beyond_4gib_without_flush(da, ctx):
     for _ in range(reps):
         for o in range(0, len(block), 32 << 20):
             enc.write_all(block[o:o + (32 << 20)])
-            held = max(held, L.mi355_debug_stream_held(enc._s))
+            held = max(held, L.mi355_deflate_stream_held_bytes(enc._s))
     enc.finish()
     assert sink.d.eof and sink.pos == reps * len(block)  # (zlib has checked the Adler-32 of all 4.25 GiB)
     assert held < (512 << 20) + (96 << 20), held
@@ -819,7 +815,7 @@ def test_input_beyond_2_31(da, ctx):
     import hashlib
     import json
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long_digest.json")))["digest"]
-    _set_long(da, 512 << 20, (1 << 30) + 1)
+    _set_long(ctx, 512 << 20, (1 << 30) + 1)
     data = datagen.webtext(gold["in_len"])
     assert hashlib.sha256(data).hexdigest() == gold["in_sha256"]
     got = ctx.encode(data, da.Compression.Default)
@@ -1055,32 +1051,133 @@ def test_issue_44_on_the_gpu(da, ctx):
         assert zlib.decompress(got) == data
 
 
-# k_sort's three ways to rank a key among the wave's keys of its digit -- ballots (MODE 0), returning LDS atomics in two
-# passes (MODE 1, the default on a device that passes k_lds_order_test) and one pass in position order (MODE 2) -- must give
-# the same sorted arrays, hence the same stream: text, runs of one byte, noise, a partial last epoch, a hash re-warm (Q1).
-# The mode is read when a context is made.
+# k_sort's two ways to rank a key among the wave's keys of its digit -- ballots (MI355_CFG_SORT_RANKS 0) and returning LDS
+# atomics (1, the default on a device that passes k_lds_order_test) -- must give the same sorted arrays, hence the same
+# stream: text, runs of one byte, noise, a partial last epoch, a hash re-warm (Q1).
 def test_sort_modes_agree(da):
     inputs = [datagen.text_like(3_000_000, 0x5157), bytes(700_001), datagen.mixed(2_500_000, 0x77), datagen.rng_bytes(300_003, 5),
               (b"ab" * 40000 + datagen.text_like(200_000, 9))[:250_017], open(os.path.join(FIX, "pg11.txt"), "rb").read()]
-    old = os.environ.get("MI355_SORT_RTN")
+    for mode in (0, 1, None):
+        c = da.Context(0)
+        try:
+            if mode is not None:
+                c.config(c.CFG_SORT_RANKS, mode)
+            for data in inputs:
+                for lv in ("default", "fast", "best"):
+                    agree(da, c, data, *LV[lv])
+        finally:
+            c.close()
+
+
+# The ranks from LDS atomics rest on the order in which the hardware serves the lanes of one atomic -- sampled by a
+# self-test when a context is made, and CHECKED on the data of every encode: k_match3 looks at every entry of a hash
+# bucket and the one before it.  The test build of the library (make debug, -DMI355_DEBUG_HOOKS) can make k_sort swap
+# two neighbours of a bucket, as a device with another order would: the encode must notice, sort again with ballot
+# ranks, give the oracle's bytes, and the context must stay on ballots.
+def test_sort_order_is_checked_on_the_data():
+    import subprocess
+    pkg = os.path.join(ROOT, "deflate-rs_amd")
+    lib = os.path.join(pkg, "libmi355deflate_dbg.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", pkg, "-s", "debug"])
+    L = C.CDLL(lib)
+    import deflate_amd as da
+    u8p = C.POINTER(C.c_uint8)
+    L.mi355_deflate_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mi355_deflate_ctx_destroy.argtypes = [C.c_void_p]
+    L.mi355_deflate_ctx_destroy.restype = None
+    L.mi355_deflate_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(da.Opts), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_deflate_bound.argtypes = [C.c_size_t]
+    L.mi355_deflate_bound.restype = C.c_size_t
+    L.mi355_debug_break_sort.argtypes = [C.c_void_p, C.c_int]
+    L.mi355_debug_sort_ranks.argtypes = [C.c_void_p]
+    L.mi355_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,
+                                    C.POINTER(da.Opts), C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mi355_shard_end.argtypes = [C.c_void_p]
+    L.mi355_shard_end.restype = None
+
+    def encode(h, data, opts):
+        cap = L.mi355_deflate_bound(len(data))
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        rc = L.mi355_deflate_encode(h, data, len(data), C.byref(opts), out, cap, C.byref(n))
+        assert rc == 0, rc
+        return bytes(out[:n.value])
+
+    for data, lv in ((datagen.text_like(1_500_000, 0xB0), "default"), (datagen.text_like(40_000_000, 0xB1), "default"),
+                     (datagen.mixed(900_000, 0xB2), "best")):
+        c, l, m = LV[lv]
+        want = ob.encode(data, opts=ob.make_opts(c, l, m, 0))
+        opts = da.CompressionOptions(c, l, m).to_c()
+        h = C.c_void_p()
+        assert L.mi355_deflate_ctx_create(0, C.byref(h)) == 0
+        try:
+            if L.mi355_debug_sort_ranks(h) != 1:
+                pytest.skip("this device sorts with ballot ranks: nothing to break")
+            assert encode(h, data, opts) == want  # the test build, unbroken
+            assert L.mi355_debug_sort_ranks(h) == 1
+            assert L.mi355_debug_break_sort(h, 1) == 0
+            assert encode(h, data, opts) == want, "the order check did not catch the broken sort"
+            assert L.mi355_debug_sort_ranks(h) == 0, "the context did not fall back to ballot ranks"
+            assert encode(h, data, opts) == want
+        finally:
+            L.mi355_deflate_ctx_destroy(h)
+    # the phases of a sharded encode check as well (mi355_shard_begin)
+    import torch
+    data = datagen.text_like(3_000_000, 0xB3)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    h = C.c_void_p()
+    assert L.mi355_deflate_ctx_create(0, C.byref(h)) == 0
     try:
-        for mode in ("0", "1", "2", None):
-            if mode is None:
-                os.environ.pop("MI355_SORT_RTN", None)
-            else:
-                os.environ["MI355_SORT_RTN"] = mode
-            c = da.Context(0)
-            try:
-                for data in inputs:
-                    for lv in ("default", "fast", "best"):
-                        agree(da, c, data, *LV[lv])
-            finally:
-                c.close()
+        assert L.mi355_debug_break_sort(h, 1) == 0
+        sh = C.c_void_p()
+        o = da.CompressionOptions.default().to_c()
+        assert L.mi355_shard_begin(h, t.data_ptr(), len(data), 0, len(data), 0, len(data), C.byref(o), None, C.byref(sh)) == 0
+        L.mi355_shard_end(sh)
+        assert L.mi355_debug_sort_ranks(h) == 0
     finally:
-        if old is None:
-            os.environ.pop("MI355_SORT_RTN", None)
-        else:
-            os.environ["MI355_SORT_RTN"] = old
+        L.mi355_deflate_ctx_destroy(h)
+
+
+# a never-flushed stream keeps a range pending between write() calls -- tokens, workspace and staged input
+# of that range -- while the context it was made on (often the shared default one) runs whatever else the process
+# encodes.  The ranges therefore live on contexts of the stream's own: two long streams and one-shot calls interleaved
+# on ONE context, noise in the data so that Stored blocks cross the seams (their bytes are read from the staged input
+# at pack time), and checksum() asked for while a range is pending.
+def test_long_streams_interleave_on_one_context(da, ctx, small_ranges):
+    import io
+    a = datagen.rng_bytes(9_000_000, 0xA1) + datagen.text_like(30_000_000, 0xA2) + datagen.rng_bytes(21_000_000, 0xA3)
+    b = datagen.text_like(25_000_000, 0xA4) + datagen.rng_bytes(30_000_000, 0xA5)
+    small = datagen.text_like(3_000_000, 0xA6)
+    big = datagen.mixed(24_000_000, 0xA7)  # (a one-shot call that goes through ranges itself)
+    want_small = ob.encode(small, level=ob.DEFAULT)
+    want_big = ob.encode(big, level=ob.DEFAULT)
+    ea = da.ZlibEncoder(io.BytesIO(), da.Compression.Default, ctx)
+    eb = da.GzEncoder(io.BytesIO(), da.Compression.Default, ctx)
+    ra = ob.Stream(ob.make_opts(128, 32, 1, 1))
+    rb = ob.Stream(ob.make_opts(128, 32, 1, 2))
+    rb.gzip_header(da.BLANK_GZIP_HEADER)
+    pa = pb = 0
+    step = 6_000_000
+    k = 0
+    while pa < len(a) or pb < len(b):
+        if pa < len(a):
+            ea.write_all(a[pa:pa + step])
+            ra.write_all(a[pa:pa + step])
+            pa += step
+        assert ctx.encode(small, da.Compression.Default) == want_small
+        if pb < len(b):
+            eb.write_all(b[pb:pb + step + 1])
+            rb.write_all(b[pb:pb + step + 1])
+            pb += step + 1
+        if k % 3 == 1:
+            assert ea.checksum() == ra.checksum()
+            assert eb.checksum() == rb.checksum()
+        if k == 4:
+            assert ctx.encode(big, da.Compression.Default) == want_big
+        k += 1
+    assert ea.finish().getvalue() == ra.finish()
+    assert eb.finish().getvalue() == rb.finish()
 
 
 # a slice of tools/fuzz_shard.py: random data kind, size, level and 2-8 virtual ranks (also ranges shorter than a

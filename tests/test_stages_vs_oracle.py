@@ -157,10 +157,11 @@ def test_q13_stored_after_slide_is_replicated():
     assert hit >= 1
 
 
-# The formulations of the chain walk in stages.h (single, multi-chain, parked, sorted runs = mode 4, their predicated form = mode 5, the pair-table form of k_match3 = mode 6) must give the
+# The formulations of the chain walk in stages.h (single, multi-chain, parked, the pair-table form of k_match3 = mode 6, with its
+# run-of-one-byte service = mode 7) must give the
 # same match table and the same stream; mode 3 additionally cuts every compare short so that the
 # "stay parked, continue at the next service" path of the GPU policy is exercised.
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [1, 2, 3, 6, 7])
 def test_match_walk_formulations_agree(mode):
     cases = [datagen.text_like(200000, 3), datagen.mixed(150000, 5), datagen.rng_bytes(70000, 2), bytes(70000),
              b"abcabcabcabc", (datagen.rng_bytes(300, 5) * 400)]
