@@ -176,7 +176,7 @@ def main():
     d_ext = None
     if shard_mode == "p1":
         # The one big input is the concatenation of the ranks' shards; a rank also holds 32 KiB of history
-        # from its left neighbour and 66 KiB of look-ahead from its right one (exchanged once, untimed).
+        # from its left neighbour and 128 KiB of look-ahead from its right one (exchanged once, untimed).
         layout = shard.p1_layout(total, rank, world)
         parts = []
         if rank > 0:

@@ -3092,3 +3092,4 @@ __global__ void k_gzip_frame(DevScalars* sc, uint8_t* out, const uint8_t* hdr, u
 #include "deflate_host.inc"
 #include "deflate_shard.inc"
 #include "deflate_long.inc"
+#include "deflate_multi.inc"

@@ -168,6 +168,20 @@ def load():
     L.mi355_checksum_combine.restype = C.c_uint32
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
+    L.mi355_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.mi355_multi_destroy.argtypes = [C.c_void_p]
+    L.mi355_multi_destroy.restype = None
+    L.mi355_multi_devices.argtypes = [C.c_void_p]
+    L.mi355_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.mi355_multi_ctx.restype = C.c_void_p
+    L.mi355_multi_last_error.argtypes = [C.c_void_p]
+    L.mi355_multi_last_error.restype = C.c_char_p
+    L.mi355_multi_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_uint64)] * 4
+    L.mi355_deflate_encode_multi.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t, u8p,
+                                             C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_deflate_encode_multi_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(Opts), C.c_char_p,
+                                                    C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi355_multi_last_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
     L.mi355_deflate_ctx_config.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     L.mi355_deflate_stream_held_bytes.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_held_bytes.restype = C.c_uint64
@@ -191,6 +205,8 @@ EXPORTED = [
     "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
     "mi355_deflate_ctx_config", "mi355_deflate_stream_held_bytes",
+    "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_devices", "mi355_multi_ctx", "mi355_multi_last_error",
+    "mi355_multi_layout", "mi355_deflate_encode_multi", "mi355_deflate_encode_multi_device", "mi355_multi_last_trace",
 ]
 
 
@@ -530,6 +546,91 @@ class GzEncoder(_Encoder):
 # ---- sharded, stream-exact encode: the per-rank phases (mi355_shard_*) -------------------------------
 ZONE = 576
 BLOCK_TOKENS = 31744
+
+
+class MultiGpu:
+    """mi355_multi: one input over several GPUs of this node in one call (one process, a thread per device); the
+    stream is the one a single encoder produces for the whole input.  devices: HIP device per rank (a device may be
+    named more than once: the ranks then share it)."""
+    TRACE = ["tables", "wait1", "tokens", "wait2", "block costs", "wait3", "plan+pack+copy", "wait4", "seams+framing",
+             "host work of the exchanges", "call"]
+
+    def __init__(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = load().mi355_multi_create(arr, len(devices), C.byref(h))
+        if rc != OK:
+            raise DeflateError(rc, "cannot create contexts on HIP devices %r" % (list(devices),))
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mi355_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        raise DeflateError(rc, load().mi355_multi_last_error(self._h).decode())
+
+    def layout(self, in_len, rank):
+        """-> dict(n_ranks, g_lo, g_hi, lo, hi): the bytes rank `rank` holds and owns"""
+        n = C.c_int(0)
+        v = [C.c_uint64(0) for _ in range(4)]
+        rc = load().mi355_multi_layout(self._h, in_len, rank, C.byref(n), *[C.byref(x) for x in v])
+        if rc != OK:
+            self._err(rc)
+        return dict(n_ranks=n.value, g_lo=v[0].value, g_hi=v[1].value, lo=v[2].value, hi=v[3].value)
+
+    def encode(self, data, options=Compression.Default, wrapper=0, compat=0, gzip_header=None):
+        """deflate_bytes_conf / _zlib_conf / _gzip_conf over all devices: bytes in, bytes out"""
+        data = bytes(data) if not isinstance(data, bytes) else data
+        o = CompressionOptions.from_(options).to_c(wrapper, compat, FLUSH_FINISH)
+        hdr = bytes(gzip_header) if gzip_header is not None else None
+        cap = load().mi355_deflate_bound_ex(len(data), wrapper, len(hdr) if hdr else 10, 0) + 8
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        rc = load().mi355_deflate_encode_multi(self._h, data, len(data), C.byref(o), hdr, len(hdr) if hdr else 0, out, cap, C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return bytes(out[:n.value])
+
+    def encode_host_ptr(self, in_ptr, n, out_ptr, out_cap, options=Compression.Default, wrapper=0):
+        o = CompressionOptions.from_(options).to_c(wrapper, 0, FLUSH_FINISH)
+        got = C.c_size_t(0)
+        rc = load().mi355_deflate_encode_multi(self._h, C.cast(C.c_void_p(in_ptr), C.c_char_p), n, C.byref(o), None, 0,
+                                               C.cast(C.c_void_p(out_ptr), C.POINTER(C.c_uint8)), out_cap, C.byref(got))
+        if rc != OK:
+            self._err(rc)
+        return got.value
+
+    def encode_device(self, d_ext_ptrs, in_len, d_out_ptr, out_cap, options=Compression.Default, wrapper=0, compat=0,
+                      gzip_header=None):
+        """d_ext_ptrs[r] = device pointer (on rank r's device) to the bytes layout(in_len, r) names; d_out on rank 0's"""
+        o = CompressionOptions.from_(options).to_c(wrapper, compat, FLUSH_FINISH)
+        hdr = bytes(gzip_header) if gzip_header is not None else None
+        arr = (C.c_void_p * len(d_ext_ptrs))(*[C.c_void_p(p) for p in d_ext_ptrs])
+        n = C.c_size_t(0)
+        rc = load().mi355_deflate_encode_multi_device(self._h, arr, in_len, C.byref(o), hdr, len(hdr) if hdr else 0,
+                                                      C.c_void_p(d_out_ptr), out_cap, C.byref(n))
+        if rc != OK:
+            self._err(rc)
+        return n.value
+
+    def trace(self):
+        t = (C.c_double * 11)()
+        load().mi355_multi_last_trace(self._h, t, 11)
+        return dict(zip(self.TRACE, [round(x, 4) for x in t]))
+
+    def rank_info(self, rank):
+        info = Info()
+        load().mi355_deflate_last_info(C.c_void_p(load().mi355_multi_ctx(self._h, rank)), C.byref(info))
+        return {"match_ms": info.match_ms, "match_launches": info.match_launches}
 
 
 class Shard:

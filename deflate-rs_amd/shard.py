@@ -5,7 +5,7 @@ Two ways, DESIGN.md section 6:
 
 * stream-exact ("P1", the default of bench.py): the ranks together produce the very bytes one
   encoder produces for the whole input.  Every rank runs links / match / parse steps on its own
-  byte range (+32 KiB history, +66 KiB look-ahead) and four small exchanges place it in the global
+  byte range (+32 KiB history, +128 KiB look-ahead) and four small exchanges place it in the global
   stream: exit tables (parse entry), token counts (+ the <= 31 743 tokens of a block that straddles
   two ranks), per-block costs (every rank then runs the same serial block plan), and the final
   OR-stitch of the packed byte ranges onto rank 0.  p1_* / encode_p1_* below.
@@ -67,7 +67,8 @@ def stitch(local_out, local_len, rank, world, group=None):
 # count, at most 31743 x 4 bytes of straddling tokens and 48 bytes per block of costs per rank.
 # =====================================================================================================
 HISTORY = 32768          # bytes of history in front of a rank's range (the match window)
-LOOKAHEAD = 66 * 1024    # bytes behind it: 258 of match look-ahead + room for a stored straddling block
+LOOKAHEAD = 128 * 1024   # bytes behind it: 258 of match look-ahead + a Stored block that begins in the range (a block of
+                         # more than ~110 KB is never Stored: 31 744 tokens take less in the fixed code) -- as deflate_long.inc
 BLOCK_TOKENS = 31744
 ZONE = 576
 

@@ -192,7 +192,8 @@ int mi355_deflate_last_blocks(mi355_deflate_ctx* ctx, mi355_block_info* out, siz
 /* ---- sharded encode: ONE input over several GPUs, stream-exact (P1) ---------------------------
  * Rank r holds in device memory the bytes [global_lo, global_lo + n_ext) of the input: its own range
  * [parse_lo, parse_hi) (buffer coordinates; parse_lo = 32768 of history except on the first rank,
- * global_lo a multiple of 32768) plus >= 66 KiB of look-ahead except on the last rank.  What the
+ * global_lo a multiple of 32768) plus >= 128 KiB of look-ahead except on the last rank (258 bytes of match
+ * look-ahead, and a Stored block that begins in the range -- never more than ~110 KB -- must end inside it).  What the
  * reference's single loop threads through the stream (src/lz77.rs parse state, the 31744-value block
  * counter src/output_writer.rs:19, the bit position src/compress.rs:167) is exchanged between the
  * phases: a 576-entry exit table, token counts, <= 31743 straddling tokens, per-block costs.
@@ -204,7 +205,8 @@ int mi355_deflate_last_blocks(mi355_deflate_ctx* ctx, mi355_block_info* out, siz
  *   4. blocks     histogram + Huffman per owned block -> cost records; all-gather
  *   5. mi355_plan_blocks (host, every rank, identical result) -> block types and global bit offsets
  *   6. pack       the rank's blocks at their global bit offsets; byte ranges are OR-stitched on rank 0
- * deflate-rs_amd/shard.py drives this over torch.distributed. */
+ * deflate-rs_amd/shard.py drives this over torch.distributed (one process per GPU); mi355_deflate_encode_multi
+ * below drives it inside the library (one process, one thread per GPU). */
 typedef struct mi355_shard mi355_shard;
 typedef struct {
     uint64_t dyn_bits, dyn_est, static_est, fixed_bits, in_bytes;
@@ -234,6 +236,45 @@ void mi355_shard_end(mi355_shard* s);
  * rank order with this and frames the stitched raw stream.  kind 1 = Adler-32, 2 = CRC-32;
  * returns checksum(A || B) from checksum(A), checksum(B) and |B|. */
 uint32_t mi355_checksum_combine(int kind, uint32_t sum_a, uint32_t sum_b, uint64_t len_b);
+
+/* ---- ONE input over the GPUs of a node in ONE call (stream-exact) -----------------------------------------
+ * deflate_bytes_conf / deflate_bytes_zlib_conf / deflate_bytes_gzip_conf (src/lib.rs:137-147, 182-198, 242-267) with
+ * several devices behind them: one process, one context and one host thread per device.  The input is cut into
+ * contiguous ranges of whole 32 KiB windows, one per device (each device also holds 32 KiB of history and 128 KiB of
+ * look-ahead: read from the host buffer, no GPU-to-GPU traffic); every device runs the phases of the sharded encode
+ * above on its range, what they exchange -- exit tables, token counts and head tokens, block costs: kilobytes --
+ * goes through host memory, and the packed byte ranges land at their offsets in `out`, the word two neighbours share
+ * OR-ed in.  The bytes are those of ONE encoder over the whole input, i.e. the reference's.
+ *   _create    devices[i] = HIP device of rank i (a device may be named more than once: ranks then share it --
+ *              how a one-GPU box tests the N-rank path); n_devices <= 64
+ *   _encode_multi         host buffers in and out (ctx-less: the handle owns its contexts); wrapper 0 / 1 / 2 as in
+ *              mi355_deflate_opts, `gz_hdr` = GzBuilder::into_header() for wrapper 2 (NULL: the blank header);
+ *              out_cap >= mi355_deflate_bound_ex(in_len, wrapper, gz_len, 0); an input of less than 1 MiB per
+ *              device uses fewer devices (down to the plain single-device call)
+ *   _layout    which bytes rank `rank` holds for an input of in_len bytes: [g_lo, g_hi) of the input, of which
+ *              [lo, hi) is its own range; *n_ranks = the ranks that take part (rank >= *n_ranks: nothing)
+ *   _encode_multi_device  the same with the input already resident: d_ext[r] = device pointer, on rank r's device,
+ *              to the bytes [g_lo, g_hi) of _layout (+ 64 readable bytes behind them); d_out = device buffer on
+ *              rank 0's device (4-byte aligned).  The packed ranges reach it by peer copies (hipMemcpyPeer: xGMI
+ *              between the GPUs of a node) -- the only GPU-to-GPU traffic of the call
+ *   _ctx       rank r's context (mi355_deflate_last_info of it: that rank's match-kernel time ...)
+ *   _last_trace  rank 0's wall clock of the last call in ms: [0] bytes + tables, [1] wait, [2] entry + tokens,
+ *              [3] wait, [4] block costs, [5] wait, [6] plan + pack + copy-out, [7] wait, [8] seams + framing,
+ *              [9] host work of the exchanges (entries, token plan, tails, block plan, seams), [10] the whole call */
+typedef struct mi355_multi mi355_multi;
+int mi355_multi_create(const int* devices, int n_devices, mi355_multi** out);
+void mi355_multi_destroy(mi355_multi* m);
+int mi355_multi_devices(const mi355_multi* m);
+mi355_deflate_ctx* mi355_multi_ctx(mi355_multi* m, int rank);
+const char* mi355_multi_last_error(mi355_multi* m);
+int mi355_multi_layout(const mi355_multi* m, size_t in_len, int rank, int* n_ranks, uint64_t* g_lo, uint64_t* g_hi,
+                       uint64_t* lo, uint64_t* hi);
+int mi355_deflate_encode_multi(mi355_multi* m, const uint8_t* in, size_t in_len, const mi355_deflate_opts* opts,
+                               const uint8_t* gz_hdr, size_t gz_len, uint8_t* out, size_t out_cap, size_t* out_len);
+int mi355_deflate_encode_multi_device(mi355_multi* m, const void* const* d_ext, size_t in_len,
+                                      const mi355_deflate_opts* opts, const uint8_t* gz_hdr, size_t gz_len, void* d_out,
+                                      size_t out_cap, size_t* out_len);
+int mi355_multi_last_trace(const mi355_multi* m, double* ms, size_t cap);
 
 /* The gzip forms (cargo feature "gzip").  `hdr` = the bytes GzBuilder::into_header() returned: the
  * header comes from the crate gzip-header 1.0, which is not part of the reference tree, so the shim

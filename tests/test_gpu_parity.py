@@ -432,6 +432,72 @@ def test_p1_sharded_ranges_shorter_than_a_block(da):
             c.close()
 
 
+# ---- SURVEY section 8 row h: ONE input over N devices in ONE call of the C ABI (mi355_deflate_encode_multi) ----
+# One process, a context and a host thread per rank; here the ranks share device 0 (what a one-GPU box can run: the
+# phases, the exchanges through host memory, the seam words and the framing are the code an 8-GPU node runs, only the
+# kernels of the ranks queue on one device and the peer copy is a device-to-device copy).
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_multi_gpu_encode_in_one_call(da, world):
+    m = da.MultiGpu([0] * world)
+    try:
+        cases = [("text", datagen.text_like(14_000_000, 0xC1), ("default", "fast", "best")),
+                 ("mixed", datagen.mixed(9_500_000, 0xC2), ("default",)),
+                 ("noise", datagen.rng_bytes(8_388_608 + 12345, 0xC3), ("default",)),   # stored blocks across every seam, Q1
+                 ("zeros", bytes(12_000_000), ("default", "rle")),                      # ranges shorter than a block
+                 ("period", (datagen.rng_bytes(300, 3) * 40000)[:9_000_001], ("fast", "huffman_only")),
+                 ("short", datagen.text_like(1_500_000, 0xC4), ("default",)),            # fewer ranks than devices
+                 ("tiny", b"hello hello hello", ("default",)), ("empty", b"", ("default",))]
+        for name, data, levels in cases:
+            for lv in levels:
+                c, l, mt = LV[lv]
+                o = da.CompressionOptions(c, l, mt)
+                want = ob.encode(data, opts=ob.make_opts(c, l, mt, 0))
+                got = m.encode(data, o)
+                assert got == want, "%s/%s over %d ranks: %d vs %d bytes" % (name, lv, world, len(got), len(want))
+        # zlib and gzip framing: every rank sums its own range, the sums are folded in rank order
+        data = datagen.text_like(11_000_000, 0xC5) + datagen.rng_bytes(700_000, 0xC6)
+        c, l, mt = LV["default"]
+        assert m.encode(data, da.Compression.Default, wrapper=1) == ob.encode(data, opts=ob.make_opts(c, l, mt, 1))
+        assert zlib.decompress(m.encode(data, da.Compression.Default, wrapper=1)) == data
+        hdr = da.BLANK_GZIP_HEADER
+        assert m.encode(data, da.Compression.Default, wrapper=2) == ob.encode_gzip(data, hdr, opts=ob.make_opts(c, l, mt, 0))
+        hdr2 = bytes([0x1f, 0x8b, 8, 8, 1, 2, 3, 4, 0, 3]) + b"name.txt\0"
+        assert m.encode(data, da.Compression.Default, wrapper=2, gzip_header=hdr2) == ob.encode_gzip(
+            data, hdr2, opts=ob.make_opts(c, l, mt, 0))
+        lay = [m.layout(len(data), r) for r in range(world)]
+        assert lay[0]["n_ranks"] == world and lay[0]["lo"] == 0 and lay[-1]["hi"] == len(data)
+        assert all(lay[r]["hi"] == lay[r + 1]["lo"] and lay[r + 1]["lo"] % 32768 == 0 for r in range(world - 1))
+    finally:
+        m.close()
+
+
+def test_multi_gpu_encode_device_resident(da):
+    """The same call with every rank's bytes already on its device and the stream assembled in rank 0's device memory:
+    the packed ranges arrive by peer copies, the seam words by one small kernel."""
+    import torch
+    for world in (2, 4):
+        m = da.MultiGpu([0] * world)
+        try:
+            for data, lv, wrapper in ((datagen.text_like(9_000_000, 0xD1), "default", 0), (datagen.mixed(7_000_000, 0xD2), "best", 1),
+                                      (bytes(10_000_000), "default", 2), (datagen.rng_bytes(5_000_000, 0xD3), "default", 0)):
+                c, l, mt = LV[lv]
+                bufs = []
+                for r in range(world):
+                    L = m.layout(len(data), r)
+                    bufs.append(torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(64), dtype=torch.uint8).cuda())
+                cap = da.bound(len(data)) + 64
+                d_out = torch.full((cap,), 0xAA, dtype=torch.uint8, device="cuda")  # (nothing relies on a cleared buffer)
+                n = m.encode_device([b.data_ptr() for b in bufs], len(data), d_out.data_ptr(), cap, da.CompressionOptions(c, l, mt),
+                                    wrapper=wrapper)
+                want = ob.encode(data, opts=ob.make_opts(c, l, mt, wrapper)) if wrapper < 2 else ob.encode_gzip(
+                    data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, mt, 0))
+                assert bytes(d_out[:n].cpu().numpy()) == want, (world, lv, wrapper)
+                t = m.trace()
+                assert t["call"] > 0
+        finally:
+            m.close()
+
+
 def _p1_dist_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
