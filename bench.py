@@ -109,6 +109,90 @@ def cpu_baselines(data, olvl, level_name):
             "zlib6_anchor": {"value": round(z6, 2), "unit": "MB/s", "cores": 1, "note": "system zlib -6, not the reference"}}
 
 
+def single_process(args, da):
+    """N GPUs of the node, ONE process: the library shards the input itself (row h of SURVEY section 8).  Weak scaling like
+    the multi-process form: every device owns `size` bytes of one N x size input, resident in its HBM with its history and
+    look-ahead; the stream lands in device 0's memory.  value = N x size bytes / step."""
+    import torch
+    N = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    devs = [0] * N if args.virtual else list(range(N))
+    if not args.virtual and ndev < N:
+        raise SystemExit("--gpus %d but %d devices visible (use --virtual for a one-GPU dry run)" % (N, ndev))
+    size = args.size or {"enwik8": 100_000_000, "webtext": 1 << 30}.get(args.workload, 100_000_000)
+    size = (size + 32767) // 32768 * 32768
+    total = N * size
+    lvl = args.level or "default"
+    options = {"default": da.CompressionOptions.default, "best": da.CompressionOptions.high,
+               "fast": da.CompressionOptions.fast}[lvl]()
+    level_name = {"default": "Compression::Default", "best": "Compression::Best", "fast": "Compression::Fast"}[lvl]
+    m = da.MultiGpu(devs)
+    lay = [m.layout(total, r) for r in range(N)]
+    assert lay[0]["n_ranks"] == N
+    # every rank makes its own bytes [g_lo, g_hi): its part of the one input, the last 32 KiB of the part before, the first
+    # 128 KiB of the part behind
+    bufs = []
+    part = {}
+
+    def piece(r):
+        if r not in part:
+            part[r] = make_input(args.workload, size, r)
+        return part[r]
+    for r in range(N):
+        L = lay[r]
+        b = bytearray()
+        p = L["g_lo"]
+        while p < L["g_hi"]:
+            q = p // size
+            e = min(L["g_hi"], (q + 1) * size)
+            b += piece(q)[p - q * size:e - q * size]
+            p = e
+        bufs.append(torch.frombuffer(b + bytearray(64), dtype=torch.uint8).to("cuda:%d" % devs[r]))
+        for k in [k for k in part if k < r]:
+            del part[k]
+    part.clear()
+    cap = da.bound(total) + 64
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda:%d" % devs[0])
+    ptrs = [b.data_ptr() for b in bufs]
+    n = 0
+    for _ in range(args.warmup):
+        n = m.encode_device(ptrs, total, d_out.data_ptr(), cap, options)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    traces = []
+    mm = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n = m.encode_device(ptrs, total, d_out.data_ptr(), cap, options)
+        traces.append(m.trace())
+        mm.append(max(m.rank_info(r)["match_ms"] / max(1, m.rank_info(r)["match_launches"]) for r in range(N)))
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    tr = {k: round(sum(t[k] for t in traces) / len(traces), 4) for k in traces[0]}
+    algo = size + n // N
+    k_ms = sum(mm) / len(mm)
+    res = {"metric": "MB/s raw input encoded (%s) + compressed size vs ref" % level_name,
+           "value": round(total * args.steps / elapsed / 1e6, 2), "unit": "MB/s", "n_gpus": N, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+           "data": "real" if "real" in INPUT_NOTE.get(args.workload, "") else "synthetic",
+           "config": {"workload": "%s%s: %d bytes per GPU, %s, one %d-byte input sharded over %d %s in ONE process "
+                                  "(mi355_deflate_encode_multi_device), stream-exact (P1), stitch by peer copies" % (
+                                      args.workload, " = " + INPUT_NOTE[args.workload] if args.workload in INPUT_NOTE else "", size,
+                                      level_name, total, N, "ranks that SHARE device 0 (dry run)" if args.virtual else "GPUs"),
+                      "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % N},
+           "out_bytes": n, "ratio": round(n / total, 5),
+           "roofline": {"bound": "hbm", "kernel": "k_match3", "achieved": round(algo / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": algo},
+           "multi_phases_ms_rank0": tr}
+    print(json.dumps(res))
+    m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +205,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the value_host_api leg (profiling runs: every kernel row is then one launch shape)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without torch.distributed: one process drives all --gpus devices through "
+                         "mi355_deflate_encode_multi_device (a thread per device inside the library)")
+    ap.add_argument("--virtual", action="store_true", help="with --single-process: the N ranks share device 0 (one-GPU dry run)")
     ap.add_argument("--pmc-file", default="", help="PMC summary to take roofline.traffic from (default: newest profiles/r*_pmc_summary.json)")
     args = ap.parse_args()
 
@@ -130,6 +218,8 @@ def main():
     import deflate_amd as da
     import shard
 
+    if args.single_process and args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return single_process(args, da)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -25,6 +25,10 @@ pub struct Ctx {
 pub struct Stream {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct Multi {
+    _p: [u8; 0],
+}
 
 extern "C" {
     fn mi355_deflate_bound(in_len: usize) -> usize;
@@ -43,6 +47,44 @@ extern "C" {
     fn mi355_deflate_stream_reset(s: *mut Stream, data: *mut *const u8, n: *mut usize) -> c_int;
     fn mi355_deflate_stream_gzip_header(s: *mut Stream, hdr: *const u8, n: usize) -> c_int;
     fn mi355_deflate_stream_free(s: *mut Stream);
+    // one input over all GPUs of the node in one call (include/mi355_deflate.h, "ONE input over the GPUs of a node")
+    fn mi355_multi_create(devices: *const c_int, n_devices: c_int, out: *mut *mut Multi) -> c_int;
+    fn mi355_deflate_encode_multi(m: *mut Multi, input: *const u8, in_len: usize, opts: *const Mi355Opts, gz_hdr: *const u8,
+                                  gz_len: usize, out: *mut u8, out_cap: usize, out_len: *mut usize) -> c_int;
+}
+extern "C" {
+    fn hipGetDeviceCount(n: *mut c_int) -> c_int; // libamdhip64, which libmi355deflate.so links anyway
+}
+
+/// Inputs of at least this many bytes are cut over all GPUs of the node by the one-shot functions (below it one GPU is
+/// as fast: a rank should have tens of megabytes).  MI355_DEFLATE_GPUS overrides the device count (1 = never shard).
+pub const MULTI_GPU_FROM: usize = 256 << 20;
+
+struct MultiHandle(*mut Multi);
+unsafe impl Send for MultiHandle {}
+/// the node's handle: one context and one host thread per device, made on first use and kept for the process
+fn multi() -> Option<&'static std::sync::Mutex<MultiHandle>> {
+    use std::sync::{Mutex, OnceLock};
+    static M: OnceLock<Option<Mutex<MultiHandle>>> = OnceLock::new();
+    M.get_or_init(|| unsafe {
+        let mut n: c_int = 0;
+        if hipGetDeviceCount(&mut n) != 0 {
+            return None;
+        }
+        if let Some(v) = std::env::var("MI355_DEFLATE_GPUS").ok().and_then(|v| v.parse::<c_int>().ok()) {
+            n = n.min(v);
+        }
+        if n < 2 {
+            return None;
+        }
+        let devs: Vec<c_int> = (0..n).collect();
+        let mut h: *mut Multi = std::ptr::null_mut();
+        if mi355_multi_create(devs.as_ptr(), n, &mut h) != 0 {
+            return None;
+        }
+        Some(Mutex::new(MultiHandle(h)))
+    })
+    .as_ref()
 }
 
 /// src/lz77.rs:27-37
@@ -115,6 +157,16 @@ fn one_shot(input: &[u8], o: Mi355Opts) -> Vec<u8> {
         let cap = mi355_deflate_bound(input.len());
         let mut out = Vec::<u8>::with_capacity(cap);
         let mut n = 0usize;
+        // a large input goes over all GPUs of the node: the same bytes (stream-exact), one call
+        if input.len() >= MULTI_GPU_FROM {
+            if let Some(m) = multi() {
+                let g = m.lock().unwrap();
+                let rc = mi355_deflate_encode_multi(g.0, input.as_ptr(), input.len(), &o, std::ptr::null(), 0, out.as_mut_ptr(), cap, &mut n);
+                assert!(rc == 0, "mi355_deflate_encode_multi failed: {}", rc);
+                out.set_len(n);
+                return out;
+            }
+        }
         let rc = mi355_deflate_encode(std::ptr::null_mut(), input.as_ptr(), input.len(), &o, out.as_mut_ptr(), cap, &mut n);
         assert!(rc == 0, "mi355_deflate_encode failed: {}", rc); // lib.rs:145 expect("Write error!")
         out.set_len(n);
@@ -146,6 +198,15 @@ pub fn deflate_bytes_gzip_conf<O: Into<CompressionOptions>>(input: &[u8], option
         let cap = mi355_deflate_bound_ex(input.len(), 2, h.len(), 0);
         let mut out = Vec::<u8>::with_capacity(cap);
         let mut n = 0usize;
+        if input.len() >= MULTI_GPU_FROM {
+            if let Some(m) = multi() {
+                let g = m.lock().unwrap();
+                let rc = mi355_deflate_encode_multi(g.0, input.as_ptr(), input.len(), &o, h.as_ptr(), h.len(), out.as_mut_ptr(), cap, &mut n);
+                assert!(rc == 0, "mi355_deflate_encode_multi failed: {}", rc);
+                out.set_len(n);
+                return out;
+            }
+        }
         let rc = mi355_deflate_encode_gzip(std::ptr::null_mut(), input.as_ptr(), input.len(), &o, h.as_ptr(), h.len(),
                                            out.as_mut_ptr(), cap, &mut n);
         assert!(rc == 0, "mi355_deflate_encode_gzip failed: {}", rc);
