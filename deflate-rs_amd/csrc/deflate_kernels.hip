@@ -1597,6 +1597,87 @@ __global__ __launch_bounds__(64) void k_level_down(uint32_t n, uint32_t nc, uint
     }
 }
 
+// k_tree_top: the levels of the table tree that have at most TOP_UNITS units, up AND down, in ONE launch by one workgroup:
+// their tables fit the LDS together, and as launches of their own each of them was a kernel of a few workgroups that
+// took a launch's latency (five levels up and five down for 100 MB: ten launches, six of them for 27 units).  In:
+// the tables of level `lt` (global, written by the last wide k_level_up) and the entry of the root unit; out: the entries of
+// the units of every level from the root down to lt - 1 (the level below the staged ones: its tables are read from
+// global memory, one entry per unit), and the tables above lt (the exit table of the whole range is the root's).
+constexpr uint32_t TOP_UNITS = 64;
+constexpr uint32_t TOP_LEVELS = 8;
+struct TopLevels {
+    uint32_t nl;                 // levels lt .. root
+    uint32_t count[TOP_LEVELS];  // units per level
+    uint64_t usize[TOP_LEVELS];  // positions per unit
+    uint16_t* X[TOP_LEVELS];
+    uint32_t* E[TOP_LEVELS];
+    // the level below lt (count_below == 0: lt is level 0)
+    uint32_t count_below;
+    uint64_t usize_below;
+    const uint16_t* X_below;
+    uint32_t* E_below;
+};
+__global__ __launch_bounds__(1024) void k_tree_top(uint32_t n, TopLevels t) {
+    __shared__ uint16_t sX[(TOP_UNITS + TOP_UNITS / FAN + 4) * ZONE];
+    __shared__ uint32_t sE[TOP_UNITS + TOP_UNITS / FAN + 4];
+    const uint32_t tid = threadIdx.x;
+    uint32_t off[TOP_LEVELS + 1];
+    off[0] = 0;
+    for (uint32_t l = 0; l < t.nl; l++) off[l + 1] = off[l] + t.count[l];
+    for (uint32_t i = tid; i < t.count[0] * ZONE; i += 1024) sX[i] = t.X[0][i];
+    __syncthreads();
+    // up: a unit's table = its children's tables composed (k_level_up)
+    for (uint32_t l = 0; l + 1 < t.nl; l++) {
+        const uint32_t nc = t.count[l], np = t.count[l + 1];
+        const uint64_t csize = t.usize[l];
+        for (uint32_t i = tid; i < np * ZONE; i += 1024) {
+            const uint32_t u = i / ZONE, e = i % ZONE;
+            const uint32_t c0 = u * FAN, c1 = c0 + FAN < nc ? c0 + FAN : nc;
+            uint32_t rel = e;
+            for (uint32_t c = c0; c < c1; c++) {
+                const uint64_t cstart = (uint64_t)c * csize;
+                const uint32_t sz = (uint64_t)n - cstart < csize ? (uint32_t)((uint64_t)n - cstart) : (uint32_t)csize;
+                if (rel < sz) rel = sz + sX[(off[l] + c) * ZONE + rel];
+                rel -= sz;
+            }
+            sX[(off[l + 1] + u) * ZONE + e] = (uint16_t)rel;
+            t.X[l + 1][i] = (uint16_t)rel;
+        }
+        __syncthreads();
+    }
+    // down: the entry of every child from the entry of its parent (k_level_down)
+    if (tid == 0) sE[off[t.nl - 1]] = t.E[t.nl - 1][0];
+    __syncthreads();
+    for (uint32_t l = t.nl - 1; l-- > 0;) {
+        const uint32_t nc = t.count[l], np = t.count[l + 1];
+        const uint64_t csize = t.usize[l];
+        if (tid < np) {
+            uint64_t pos = sE[off[l + 1] + tid];
+            const uint32_t c1 = (tid + 1) * FAN < nc ? (tid + 1) * FAN : nc;
+            for (uint32_t c = tid * FAN; c < c1; c++) {
+                const uint64_t cstart = (uint64_t)c * csize;
+                const uint64_t cend = cstart + csize < n ? cstart + csize : n;
+                sE[off[l] + c] = (uint32_t)pos;
+                t.E[l][c] = (uint32_t)pos;
+                if (pos < cend) pos = cend + sX[(off[l] + c) * ZONE + (uint32_t)(pos - cstart)];
+            }
+        }
+        __syncthreads();
+    }
+    if (t.count_below && tid < t.count[0]) {
+        const uint32_t nc = t.count_below;
+        const uint64_t csize = t.usize_below;
+        uint64_t pos = sE[tid];
+        const uint32_t c1 = (tid + 1) * FAN < nc ? (tid + 1) * FAN : nc;
+        for (uint32_t c = tid * FAN; c < c1; c++) {
+            const uint64_t cstart = (uint64_t)c * csize;
+            const uint64_t cend = cstart + csize < n ? cstart + csize : n;
+            t.E_below[c] = (uint32_t)pos;
+            if (pos < cend) pos = cend + t.X_below[(uint64_t)c * ZONE + (pos - cstart)];
+        }
+    }
+}
+
 // the table with the two entries at and behind position j already in registers (positions relative to `g`)
 struct NearM {
     const uint32_t* g;
