@@ -1045,8 +1045,30 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
         sb8 = (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
     }
+#define MF_ONE(F, W, C, RA, RB, R0, R1, R2, R3, R4, R5, R6, R7)                           \
+        "s_mov_b64 exec, %[" W "]\n\t"                                                      \
+        "global_load_dwordx4 " RA ", %[" F "offb], %[sb] offset:-14\n\t"                    \
+        "global_load_dwordx4 " RB ", %[" F "offb], %[sb] offset:-30\n\t"                    \
+        "s_waitcnt vmcnt(1)\n\t"                                                            \
+        MF_ISSUE8(F, R0, R1, R2, R3)                                                        \
+        MF_TEST8(F, "7", "6", "5", "4", "3", "2", "1", "0")                                 \
+        "s_cbranch_execz .Lmf_one" F "%=\n\t"                                               \
+        "s_waitcnt vmcnt(0)\n\t"                                                            \
+        MF_ISSUE8(F, R4, R5, R6, R7)                                                        \
+        MF_TEST8(F, "7", "6", "5", "4", "3", "2", "1", "0")                                 \
+        ".Lmf_one" F "%=:\n\t"                                                              \
+        "s_mov_b64 %[" C "], exec\n\t"
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
+        // towards the end of a pair of batches one fibre has often finished while the other still walks (a quarter of
+        // the blocks on text): its vector instructions would issue all the same -- an empty EXEC skips memory
+        // instructions, not vector ALU ones -- so a block for the fibre that is left
+        "s_mov_b64 %[cx], 0\n\t"
+        "s_mov_b64 %[cy], 0\n\t"
+        "s_cmp_eq_u64 %[wy], 0\n\t"
+        "s_cbranch_scc1 .Lmf_xonly%=\n\t"
+        "s_cmp_eq_u64 %[wx], 0\n\t"
+        "s_cbranch_scc1 .Lmf_yonly%=\n\t"
         "s_mov_b64 exec, %[wx]\n\t"
         "global_load_dwordx4 v[56:59], %[xoffb], %[sb] offset:-14\n\t"  // x: entries off-7 .. off
         "global_load_dwordx4 v[60:63], %[xoffb], %[sb] offset:-30\n\t"  //    off-15 .. off-8
@@ -1078,6 +1100,12 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
         "s_mov_b64 exec, %[cy]\n\t"
         MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0")
         "s_mov_b64 %[cy], exec\n\t"
+        "s_branch .Lmf_end%=\n\t"
+        ".Lmf_xonly%=:\n\t"
+        MF_ONE("x", "wx", "cx", "v[56:59]", "v[60:63]", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
+        "s_branch .Lmf_end%=\n\t"
+        ".Lmf_yonly%=:\n\t"
+        MF_ONE("y", "wy", "cy", "v[64:67]", "v[68:71]", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71")
         ".Lmf_end%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "s_mov_b64 exec, %[save]\n\t"
@@ -1085,6 +1113,7 @@ __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, cons
         : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky)
         : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",
           "v70", "v71");
+#undef MF_ONE
     *stillx = cx;
     *stilly = cy;
 }
