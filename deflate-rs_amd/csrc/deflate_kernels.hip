@@ -95,7 +95,8 @@ struct DevScalars {
 struct DevState {
     DevScalars sc;
     uint32_t sort_bad;  // k_match3 met a bucket whose entries do not ascend: k_sort's ranks from LDS atomics cannot be trusted
-    uint32_t pad[3];
+    uint32_t spec_bad;  // a segment's speculative entry (k_emit<true>) is not where the segment before it was left
+    uint32_t pad[2];
 };
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
@@ -1724,27 +1725,43 @@ struct NearM {
 // wave scan places the tokens.
 // (Segments are relative to pos0: the sharded path parses a sub-range [pos0, pos0 + n) of a buffer of
 // n_total bytes; the whole-buffer path has pos0 = 0, n = n_total.)
+//
+// SPEC: the segment's entry is not given but FOUND -- the wave starts SPEC_W positions in front of its segment, at a
+// position that need not lie on the path at all, and follows the restart steps: paths merge for good as soon as they
+// share one restart position (a step depends on nothing but its position), which on anything but long periodic data
+// happens within a few dozen bytes.  The first restart position at or behind the segment's start is taken as its entry
+// (written to E0), the parse goes on from there as usual, and where it leaves the segment is written to Xs: segment 0
+// starts at the stream's true entry, so if every segment's entry equals the exit of the segment before it (k_scan_a
+// checks) all of them are the true ones -- by induction, no probability involved -- and the exit tables of every
+// segment, the table tree above them and the way down (k_seg_exit, k_level_up, k_tree_top, k_level_down) were not
+// needed.  If one differs the host parses again the exact way.
+constexpr uint32_t SPEC_W = 256;
+template <bool SPEC>
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                               const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
-                                              const uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
-                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg) {
-    __shared__ uint16_t s_adv[4][SEG];
-    __shared__ uint16_t s_pp[4][SEG];
+                                              uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
+                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
+                                              uint32_t* __restrict__ Xs) {
+    constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
+    __shared__ uint16_t s_adv[4][REG];
+    __shared__ uint16_t s_pp[4][REG];
     __shared__ uint32_t s_np[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
-    const uint64_t a = k * SEG, b = a + SEG < n ? a + SEG : n;
+    const uint32_t w0 = (SPEC && k > 0) ? SPEC_W : 0u;
+    const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
+    const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
     const uint32_t len = (uint32_t)(b - a);
     uint16_t* A = s_adv[wv];
     uint16_t* P = s_pp[wv];
     {   // (fetched together: a load per round of a loop is a memory latency per round)
-        uint16_t av[SEG / 64];
+        uint16_t av[REG / 64];
 #pragma unroll
-        for (uint32_t q = 0; q < SEG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
+        for (uint32_t q = 0; q < REG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
 #pragma unroll
-        for (uint32_t q = 0; q < SEG / 64; q++)
+        for (uint32_t q = 0; q < REG / 64; q++)
             if (q * 64 + lane < len) A[q * 64 + lane] = av[q];
     }
     wave_lds_fence();
@@ -1770,19 +1787,27 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         // the i-th recorded position is at least 4 i: its slot lies at or before the entry just read, and the
         // chain only reads further right
         uint32_t np = 0;
-        uint64_t e = E0[k];
-        uint32_t j = e >= b ? len : (uint32_t)(e - a);
+        uint32_t j;
+        if (SPEC) {
+            j = 0;
+            while (j < w0) j += A[j];  // the run-up: single steps to the first restart position in the segment
+            E0[k] = (uint32_t)(a + j);
+        } else {
+            const uint64_t e = E0[k];
+            j = e >= b ? len : (uint32_t)(e - a);
+        }
         while (j < len) {
             const uint32_t at = j;
             j += P[at];
             P[np++] = (uint16_t)at;
         }
+        if (SPEC) Xs[k] = (uint32_t)(a + j);  // where the path leaves the segment
         s_np[wv] = np;
     }
     wave_lds_fence();
     const uint32_t np = s_np[wv];
-    uint32_t* out = tokbuf + a;
-    // (32-bit positions relative to the segment's first byte: tables, input and the end of the data)
+    uint32_t* out = tokbuf + a0;
+    // (32-bit positions relative to the first byte the wave holds: tables, input and the end of the data)
     const uint64_t sbase = (uint64_t)pos0 + a;
     const uint32_t* const Ms = M + sbase;
     const uint32_t* const Mqs = (Mq ? Mq : M) + sbase;
@@ -1854,10 +1879,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     }
     return v;
 }
-__global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ part) {
+// (E0 / Xs / spec_bad: after a speculative k_emit -- every segment's entry must be the exit of the segment before it)
+__global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ part,
+                                                 const uint32_t* __restrict__ E0, const uint32_t* __restrict__ Xs,
+                                                 uint32_t* __restrict__ spec_bad) {
     __shared__ uint32_t wtot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t i = blockIdx.x * 1024 + tid;
+    if (Xs) {
+        const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
+        if (__builtin_amdgcn_ballot_w64(off) != 0 && lane == 0) atomicOr(spec_bad, 1u);
+    }
     uint32_t v = i < K ? cnt[i] : 0;
 #pragma unroll
     for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);

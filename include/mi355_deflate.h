@@ -168,7 +168,8 @@ typedef struct {
     uint32_t q1_rewarm;       /* 1 if the hash re-warm quirk (A.4 Q1) fired and was reproduced */
     uint32_t q13_hits;        /* stored blocks hit by A.4 Q13 */
     uint32_t passes;          /* 1, or 2 when Q1 forced a second pass */
-    uint32_t reserved;
+    uint32_t spec_fallback;   /* 1: the speculative segment entries of the parse did not check out (long periodic data) and
+                                 the call was parsed again the exact way -- same bytes, about a millisecond per 100 MB more */
     float stage_ms[MI355_N_STAGES]; /* HIP-event time per stage, summed over passes */
     float total_ms;                 /* first kernel enqueued .. last kernel done */
     uint32_t match_launches;        /* launches of the dominant kernel in this encode */

@@ -432,6 +432,45 @@ def test_p1_sharded_ranges_shorter_than_a_block(da):
             c.close()
 
 
+# The parse finds every segment's entry by speculation -- a run-up of 256 positions in front of the segment, paths merge
+# for good once they share a restart position -- and CHECKS the chain of entries and exits (k_emit<true>, k_scan_a); long
+# periodic data (zero fill: a 258-byte match after the other, a path never meets the one that started a byte later) fails
+# the check, the call is parsed again with exit tables and the table tree, and the context parses that way for a while.
+# Same bytes either way.
+def test_speculative_segment_entries_and_their_fallback(da):
+    c = da.Context(0)
+    try:
+        text = datagen.text_like(5_000_000, 0xE1)
+        zeros = bytes(3_000_001)
+        per = (datagen.rng_bytes(301, 7) * 20000)[:4_000_000]
+        for lv in ("default", "fast", "best", "rle"):
+            a, l, m = LV[lv]
+            o = da.CompressionOptions(a, l, m)
+            c2 = da.Context(0)
+            try:
+                assert c2.encode(text, o) == ob.encode(text, opts=ob.make_opts(a, l, m, 0))
+                if lv != "rle":  # (the run level sees text as literals: every position a restart position)
+                    assert c2.info()["spec_fallback"] == 0, lv
+                assert c2.encode(zeros, o) == ob.encode(zeros, opts=ob.make_opts(a, l, m, 0))
+                assert c2.info()["spec_fallback"] == 1, lv
+                for _ in range(3):  # the exact parse for a while: no second attempt, no fallback
+                    assert c2.encode(per, o) == ob.encode(per, opts=ob.make_opts(a, l, m, 0))
+                    assert c2.info()["spec_fallback"] == 0
+            finally:
+                c2.close()
+        # mixed data with the seams of its pieces, every level, speculation on (a fresh context per case)
+        mix = datagen.mixed(6_000_000, 0xE2) + zeros[:700_000] + text[:900_000] + per[:500_000]
+        for lv in ("default", "fast", "best", "huffman_only"):
+            a, l, m = LV[lv]
+            c3 = da.Context(0)
+            try:
+                assert c3.encode(mix, da.CompressionOptions(a, l, m)) == ob.encode(mix, opts=ob.make_opts(a, l, m, 0)), lv
+            finally:
+                c3.close()
+    finally:
+        c.close()
+
+
 # ---- SURVEY section 8 row h: ONE input over N devices in ONE call of the C ABI (mi355_deflate_encode_multi) ----
 # One process, a context and a host thread per rank; here the ranks share device 0 (what a one-GPU box can run: the
 # phases, the exchanges through host memory, the seam words and the framing are the code an 8-GPU node runs, only the
