@@ -89,6 +89,8 @@ struct DevScalars {
     uint32_t adler;
     uint32_t crc;          // CRC-32 of the input (gzip trailer), XOR-accumulated by k_crc_fold
     uint64_t adler_a, adler_b;  // sums of the chunk contributions (k_adler_part)
+    uint32_t n_fix;        // segments whose speculative entry did not check out (k_spec_check)
+    uint32_t pad_;
 };
 
 // ... and what outlives the clearing of the scalars at the start of an encode
@@ -98,6 +100,9 @@ struct DevState {
     uint32_t spec_bad;  // a segment's speculative entry (k_emit<true>) is not where the segment before it was left
     uint32_t pad[2];
 };
+
+// (the kernels behind a speculative parse that failed its check have nothing to do: the host parses again)
+__device__ __forceinline__ bool spec_failed(const DevScalars* sc) { return reinterpret_cast<const DevState*>(sc)->spec_bad != 0; }
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
 #ifndef MI355_FAN
@@ -1735,27 +1740,49 @@ struct NearM {
 // checks) all of them are the true ones -- by induction, no probability involved -- and the exit tables of every
 // segment, the table tree above them and the way down (k_seg_exit, k_level_up, k_tree_top, k_level_down) were not
 // needed.  If one differs the host parses again the exact way.
-constexpr uint32_t SPEC_W = 256;
-template <bool SPEC>
+// MODE 2, the repair of a handful of entries that did not check out (k_spec_check lists them; a seam of pieces of
+// different kinds, a short periodic stretch): a wave per listed segment parses it again from where the segment before it
+// was left, and goes on into the next segments for as long as its exit differs from their entry (at most FIX_HOPS of them,
+// never into a segment that is listed itself: that one has a wave of its own).  What is still inconsistent afterwards --
+// chains that met, long periodic data where every boundary fails -- is seen by the final check in k_scan_a.
+constexpr uint32_t SPEC_W = 128;  // (measured with the repair in place, parse stage of the 100 MB text: 64 / 128 / 256 positions 0.59 / 0.58 / 0.63 ms;
+                                  // the Silesia-like mix 1.64 / 1.33 / 1.40 ms -- at 64 a thousand of its entries need the repair)
+constexpr uint32_t FIX_MAX = 1024;  // listed segments the repair takes on (more: the data is periodic at large, the exact parse is due)
+constexpr uint32_t FIX_HOPS = 24;
+struct SpecFix {
+    uint32_t* list;          // segments whose entry is not the exit of the segment before
+    uint32_t* badmap;        // the same as a bit per segment
+    const DevScalars* sc;    // sc->n_fix = how many
+};
+template <int MODE>
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                               const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
                                               uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
                                               uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
-                                              uint32_t* __restrict__ Xs) {
+                                              uint32_t* __restrict__ Xs, SpecFix fix) {
+    constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
     __shared__ uint16_t s_adv[4][REG];
     __shared__ uint16_t s_pp[4][REG];
-    __shared__ uint32_t s_np[4];
+    __shared__ uint32_t s_np[4], s_exit[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    uint32_t given = 0;  // MODE 2: the entry the segment is parsed from
+    if (MODE == 2) {
+        const uint32_t nf = fix.sc->n_fix;
+        if (nf > FIX_MAX || k >= nf) return;
+        k = fix.list[k];
+        given = Xs[k - 1];  // (a listed segment is never the first)
+    }
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
+    uint16_t* A = s_adv[wv];
+    uint16_t* P = s_pp[wv];
+    for (uint32_t hop = 0;; hop++) {
     const uint32_t w0 = (SPEC && k > 0) ? SPEC_W : 0u;
     const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
     const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
     const uint32_t len = (uint32_t)(b - a);
-    uint16_t* A = s_adv[wv];
-    uint16_t* P = s_pp[wv];
     {   // (fetched together: a load per round of a loop is a memory latency per round)
         uint16_t av[REG / 64];
 #pragma unroll
@@ -1793,7 +1820,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
             while (j < w0) j += A[j];  // the run-up: single steps to the first restart position in the segment
             E0[k] = (uint32_t)(a + j);
         } else {
-            const uint64_t e = E0[k];
+            const uint64_t e = MODE == 2 ? (uint64_t)given : (uint64_t)E0[k];
+            if (MODE == 2) E0[k] = given;
             j = e >= b ? len : (uint32_t)(e - a);
         }
         while (j < len) {
@@ -1801,7 +1829,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
             j += P[at];
             P[np++] = (uint16_t)at;
         }
-        if (SPEC) Xs[k] = (uint32_t)(a + j);  // where the path leaves the segment
+        if (MODE != 0) Xs[k] = (uint32_t)(a + j);  // where the path leaves the segment
+        s_exit[wv] = (uint32_t)(a + j);
         s_np[wv] = np;
     }
     wave_lds_fence();
@@ -1866,6 +1895,35 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         running += total;
     }
     if (lane == 0) cnt[k] = running;
+    if (MODE != 2) break;
+    // the repair goes on while the exit of the segment just parsed is not the entry the next one was parsed from
+    const uint32_t x = s_exit[wv];
+    wave_lds_fence();
+    k++;
+    if (k >= K || hop + 1 >= FIX_HOPS) break;
+    if ((fix.badmap[k >> 5] >> (k & 31)) & 1u) break;  // (listed: another wave's)
+    if (E0[k] == x) break;                             // the paths have met
+    given = x;
+    }
+}
+
+// k_spec_check: after the speculative k_emit, which segments were entered somewhere else than the segment before them was
+// left?  A bit per segment and a list (in no particular order) for the repair; sc->n_fix counts them.
+__global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* __restrict__ E0, const uint32_t* __restrict__ Xs,
+                                                    uint32_t* __restrict__ badmap, uint32_t* __restrict__ list, DevScalars* sc) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
+    const uint64_t m = __builtin_amdgcn_ballot_w64(off);
+    if (lane == 0) {
+        badmap[(i >> 5)] = (uint32_t)m;
+        badmap[(i >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+    if (m == 0) return;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&sc->n_fix, (uint32_t)__popcll(m));
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (off && at + rank < FIX_MAX) list[at + rank] = i;
 }
 
 // k_scan_a / k_scan_b: exclusive scan of the per-segment token counts.  A workgroup takes 1024
@@ -1888,7 +1946,8 @@ __global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __r
     const uint32_t i = blockIdx.x * 1024 + tid;
     if (Xs) {
         const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
-        if (__builtin_amdgcn_ballot_w64(off) != 0 && lane == 0) atomicOr(spec_bad, 1u);
+        const uint64_t offm = __builtin_amdgcn_ballot_w64(off);
+        if (offm != 0 && lane == 0) atomicAdd(spec_bad, (uint32_t)__popcll(offm));
     }
     uint32_t v = i < K ? cnt[i] : 0;
 #pragma unroll
@@ -1949,9 +2008,9 @@ __global__ void k_scan_zero(DevScalars* sc) {
 // k_compact: tokens of all segments into one dense stream.
 __global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __restrict__ tokbuf,
                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
-                                                 uint32_t* __restrict__ dtok) {
+                                                 uint32_t* __restrict__ dtok, const DevScalars* sc) {
     uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= K) return;
+    if (k >= K || spec_failed(sc)) return;
     uint32_t lane = threadIdx.x & 63;
     uint32_t c = cnt[k], b = base[k];
     const uint32_t* src = tokbuf + k * SEG;
@@ -2124,7 +2183,7 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
                                                     BlockTab tab) {
     __shared__ uint32_t h[320];
     const uint32_t b = blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
-    if (b >= sc->nb) return;
+    if (b >= sc->nb || spec_failed(sc)) return;
     for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
     __syncthreads();
     const uint32_t nt = tab.nt[b];
@@ -2338,7 +2397,7 @@ __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, cons
                                                       const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr) {
     __shared__ HdrLds s;
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (b >= sc->nb) return;
+    if (b >= sc->nb || spec_failed(sc)) return;
     HT_DECL
     for (uint32_t i = tid; i < 288; i += 128) {
         uint32_t f = i == END_OF_BLOCK ? 1u : 0u;  // output_writer.rs:83
@@ -2486,6 +2545,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
                                              BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
                                              const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32) {
     const uint32_t lane = threadIdx.x;
+    if (spec_failed(sc)) return;
     const uint32_t nb = sc->nb;
     uint64_t bitpos = bit_base;
     uint32_t n_st = 0, n_fx = 0, n_dy = 0, hits = 0, panic = 0;
@@ -2679,7 +2739,7 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
                                               const uint32_t* __restrict__ ll_freq, const uint32_t* __restrict__ d_freq) {
     __shared__ PackLds s;
     const uint32_t b = blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT, tid = threadIdx.x;
-    if (b >= sc->nb) return;
+    if (b >= sc->nb || spec_failed(sc)) return;
     const uint32_t gtid = part * PKT + tid;  // a stored block's bytes are spread over all parts' threads
     constexpr uint32_t GT = PKT * PSPLIT;
     const BlockPlan pl = plan[b];

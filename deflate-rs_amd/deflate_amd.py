@@ -31,7 +31,8 @@ class Info(C.Structure):
                 ("n_blocks", C.c_uint32), ("n_stored", C.c_uint32), ("n_fixed", C.c_uint32),
                 ("n_dynamic", C.c_uint32), ("q1_rewarm", C.c_uint32), ("q13_hits", C.c_uint32),
                 ("passes", C.c_uint32), ("spec_fallback", C.c_uint32), ("stage_ms", C.c_float * 6),
-                ("total_ms", C.c_float), ("match_launches", C.c_uint32), ("match_ms", C.c_float)]
+                ("total_ms", C.c_float), ("match_launches", C.c_uint32), ("match_ms", C.c_float),
+                ("spec_repaired", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BlockInfo(C.Structure):

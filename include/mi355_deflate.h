@@ -174,6 +174,8 @@ typedef struct {
     float total_ms;                 /* first kernel enqueued .. last kernel done */
     uint32_t match_launches;        /* launches of the dominant kernel in this encode */
     float match_ms;                 /* their summed duration */
+    uint32_t spec_repaired;         /* segments whose speculative entry was wrong and that were parsed again in place */
+    uint32_t reserved;
 } mi355_deflate_info;
 int mi355_deflate_last_info(mi355_deflate_ctx* ctx, mi355_deflate_info* info);
 

@@ -432,7 +432,7 @@ def test_p1_sharded_ranges_shorter_than_a_block(da):
             c.close()
 
 
-# The parse finds every segment's entry by speculation -- a run-up of 256 positions in front of the segment, paths merge
+# The parse finds every segment's entry by speculation -- a run-up of 128 positions in front of the segment, paths merge
 # for good once they share a restart position -- and CHECKS the chain of entries and exits (k_emit<true>, k_scan_a); long
 # periodic data (zero fill: a 258-byte match after the other, a path never meets the one that started a byte later) fails
 # the check, the call is parsed again with exit tables and the table tree, and the context parses that way for a while.
@@ -452,7 +452,7 @@ def test_speculative_segment_entries_and_their_fallback(da):
                 if lv != "rle":  # (the run level sees text as literals: every position a restart position)
                     assert c2.info()["spec_fallback"] == 0, lv
                 assert c2.encode(zeros, o) == ob.encode(zeros, opts=ob.make_opts(a, l, m, 0))
-                assert c2.info()["spec_fallback"] == 1, lv
+                assert c2.info()["spec_fallback"] >= 1, lv  # (the number of segment boundaries that failed the check)
                 for _ in range(3):  # the exact parse for a while: no second attempt, no fallback
                     assert c2.encode(per, o) == ob.encode(per, opts=ob.make_opts(a, l, m, 0))
                     assert c2.info()["spec_fallback"] == 0
