@@ -24,6 +24,8 @@ LAUNCHES = {}  # kernel -> launches per counter pass
 def short(name):
     n = name.replace("void ", "").replace("mi355::", "")
     n = n.split("(")[0]
+    if n.startswith("k_emit<"):  # (three kernels: 0 = entries given, 1 = speculative entries, 2 = the repair)
+        return n.split(">")[0] + ">"
     return n.split("<")[0] if n.startswith("k_") else n
 
 
@@ -104,12 +106,12 @@ def main():
     json.dump({"note": "rocprofv3 --pmc passes (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE: four separate runs) over `python bench.py "
                        "--steps 1 --warmup 0 --no-cpu-baseline --no-host-api`; per launch (launches = dispatches of the kernel in a pass); hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                        "(FETCH_SIZE doubled per MI355X_MICROARCH.md); durations from the --kernel-trace run",
-               "workload": bl["config"]["workload"].split(":")[0], "bytes_per_gpu": n,
+               "workload": bl["config"]["workload"].split(":")[0].split(" = ")[0], "bytes_per_gpu": n,
                "level": {"Compression::Default": "default", "Compression::Best": "best", "Compression::Fast": "fast", "rle()": "rle",
                          "huffman_only()": "huffman_only"}[lvl],
                "launches_per_pass": 1, "kernels": kernels}, open(os.path.join(OUT, TAG + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(open(os.path.join(OUT, TAG + "_kernel_stats.txt")).read())
-    print(json.dumps({k: {x: kernels[k].get(x) for x in ("hbm_bytes", "hbm_GBps", "lds_bank_conflict_rate", "valu_wave_instr_per_input_byte", "avg_us_kernel_trace")} for k in ("k_match3", "k_match2", "k_sort", "k_adv", "k_emit", "k_seg_exit", "k_pack") if k in kernels}, indent=1))
+    print(json.dumps({k: {x: kernels[k].get(x) for x in ("hbm_bytes", "hbm_GBps", "lds_bank_conflict_rate", "valu_wave_instr_per_input_byte", "avg_us_kernel_trace")} for k in ("k_match3", "k_sort", "k_adv", "k_emit<1>", "k_pack", "k_compact") if k in kernels}, indent=1))
 
 
 main()
