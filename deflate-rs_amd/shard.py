@@ -208,7 +208,9 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     input (+ >= 16 bytes of slack).  comm_device: where exchanged tensors live -- the GPU for the nccl
     (= RCCL) backend, "cpu" for gloo.  wrapper 1 / 2: a zlib / gzip stream (every rank sums its own range on
     its GPU, rank 0 folds the sums and frames the stitched raw stream; lib.rs:182-198, 242-267).
-    Returns (tensor on rank 0 | None, stream length in bytes).
+    Returns (tensor on rank 0 | None, stream length in bytes).  The tensor is a view of a stream image that is kept between
+    calls (nothing of stream size is allocated or cleared per step): it is valid until the next call on this process --
+    clone it to keep it.
 
     What travels, four rounds: (1) all-gather of the 576-entry exit tables, (2) all-gather
     of the token counts while the up to 31 743 head tokens go to the left neighbour, (3) ONE all-gather of a
