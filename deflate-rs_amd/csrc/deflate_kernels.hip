@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
                                               uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
                                               uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
-                                              uint32_t* __restrict__ Xs, SpecFix fix) {
+                                              uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0) {
     constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
     __shared__ uint16_t s_adv[4][REG];
@@ -1779,7 +1779,9 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     uint16_t* A = s_adv[wv];
     uint16_t* P = s_pp[wv];
     for (uint32_t hop = 0;; hop++) {
-    const uint32_t w0 = (SPEC && k > 0) ? SPEC_W : 0u;
+    // (runup0: the first segment has data in front of it as well -- a range of a sharded or long encode with its history --
+    // and finds its entry like the others; without it the first segment starts at the stream's true entry, position 0)
+    const uint32_t w0 = (SPEC && (k > 0 || runup0)) ? SPEC_W : 0u;
     const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
     const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
     const uint32_t len = (uint32_t)(b - a);

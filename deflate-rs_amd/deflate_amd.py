@@ -136,6 +136,7 @@ def load():
     L.mi355_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64,
                                     C.c_uint64, C.POINTER(Opts), C.c_void_p, C.POINTER(C.c_void_p)]
     L.mi355_shard_exit_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mi355_shard_spec.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mi355_shard_emit.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
     L.mi355_shard_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(BlockCost), C.c_size_t]
@@ -202,7 +203,7 @@ EXPORTED = [
     "mi355_deflate_ctx_reserve", "mi355_deflate_stream_gzip_header", "mi355_deflate_stream_reset",
     "mi355_deflate_encode_gzip",
     "mi355_deflate_encode_device_gzip", "mi355_crc32_device",
-    "mi355_shard_begin", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_shard_blocks_ex",
+    "mi355_shard_begin", "mi355_shard_spec", "mi355_shard_exit_table", "mi355_shard_emit", "mi355_shard_blocks", "mi355_shard_blocks_ex",
     "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
     "mi355_deflate_ctx_config", "mi355_deflate_stream_held_bytes",
@@ -649,6 +650,14 @@ class Shard:
         self._h = h
         self.compat = compat
         self.nb = 0
+
+    def spec(self):
+        """-> (held, entry, exit) of the range's speculative parse (buffer coordinates)"""
+        h, e, x = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        rc = load().mi355_shard_spec(self._h, C.byref(h), C.byref(e), C.byref(x))
+        if rc != OK:
+            self.ctx._err(rc)
+        return bool(h.value), e.value, x.value
 
     def exit_table(self):
         t = (C.c_uint32 * ZONE)()

@@ -96,6 +96,21 @@ def p1_entries(layouts, tables):
     return entries
 
 
+def p1_spec_entries(layouts, specs):
+    """The ranks' speculative parses, specs[r] = (held, entry, exit) in the rank's buffer coordinates: every range finds
+    its entry by a run-up into its history.  If every rank's chain held and every rank was entered where the rank before it
+    was left -- rank 0 at position 0 -- the entries are the true ones (induction over the ranks, as over the segments inside
+    one) -> their global positions; else None: the exit tables decide (p1_entries)."""
+    entries = []
+    prev_exit = 0
+    for L, (held, e, x) in zip(layouts, specs):
+        if not held or L["g_lo"] + e != prev_exit:
+            return None
+        entries.append(prev_exit)
+        prev_exit = L["g_lo"] + x
+    return entries
+
+
 def p1_token_split(counts):
     """From the token counts: for every rank (skip, tail) = how many of its first tokens belong to a block that
     began to its left, and how many tokens it needs from its right to complete its last block.
@@ -159,8 +174,10 @@ def encode_p1_virtual(da, ctxs, data, options=None, compat=0):
         bufs.append(t)
         shards.append(da.Shard(ctxs[r], t.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total,
                                options, compat))
-    tables = [s.exit_table() for s in shards]                                  # exchange 1
-    entries = p1_entries(lay, tables)
+    entries = p1_spec_entries(lay, [s.spec() for s in shards])                 # exchange 0: three numbers per rank
+    if entries is None:
+        tables = [s.exit_table() for s in shards]                              # exchange 1 (periodic data: the exact way)
+        entries = p1_entries(lay, tables)
     toks = [shards[r].emit(entries[r] - lay[r]["g_lo"]) for r in range(world)]  # (count, dptr)
     counts = [c for c, _ in toks]                                              # exchange 2
     skip, tail, owns, pieces = p1_token_plan(counts)
@@ -239,15 +256,24 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     mark("start")
     sh = da.Shard(ctx, d_ext.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], total, options, compat,
                   torch.cuda.current_stream(dev).cuda_stream)
-    mark("chains, match table, exit tables")
-    # round 1: exit tables -> entry positions
-    mine = torch.tensor(sh.exit_table(), dtype=torch.int32, device=cdev)
-    allv = torch.empty(world * ZONE, dtype=torch.int32, device=cdev)
-    dist.all_gather_into_tensor(allv, mine, group=group)
-    tables = allv.view(world, ZONE).tolist()
+    mark("chains, match table, speculative parse")
     lays = [p1_layout(total, r, world) for r in range(world)]
-    entries = p1_entries(lays, tables)
-    mark("x1 exit tables")
+    # round 0: did every rank's speculative parse hold, and do the ranks' entries and exits form one chain?  Then the tokens
+    # are there and no exit table is made (every rank decides the same from the same numbers)
+    held, e_in, e_out = sh.spec()
+    mine0 = torch.tensor([int(held), e_in, e_out], dtype=torch.int64, device=cdev)
+    all0 = torch.empty(world * 3, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(all0, mine0, group=group)
+    entries = p1_spec_entries(lays, [(bool(h), e, x) for h, e, x in all0.view(world, 3).tolist()])
+    mark("x0 entries and exits")
+    if entries is None:
+        # round 1: exit tables -> entry positions
+        mine = torch.tensor(sh.exit_table(), dtype=torch.int32, device=cdev)
+        allv = torch.empty(world * ZONE, dtype=torch.int32, device=cdev)
+        dist.all_gather_into_tensor(allv, mine, group=group)
+        tables = allv.view(world, ZONE).tolist()
+        entries = p1_entries(lays, tables)
+        mark("x1 exit tables")
     n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
     mark("emit")
     # round 2: token counts and the head of every rank's tokens (a rank may need up to 31 743 tokens from its right

@@ -200,10 +200,16 @@ int mi355_deflate_last_blocks(mi355_deflate_ctx* ctx, mi355_block_info* out, siz
  * reference's single loop threads through the stream (src/lz77.rs parse state, the 31744-value block
  * counter src/output_writer.rs:19, the bit position src/compress.rs:167) is exchanged between the
  * phases: a 576-entry exit table, token counts, <= 31743 straddling tokens, per-block costs.
- *   1. begin      links, match table, restart steps, exit table of [parse_lo, parse_hi)
- *   2. exit_table X[e] = where the parse leaves the range (offset beyond parse_hi) if it enters at
- *                 parse_lo + e;  all-gather, then every rank knows its entry position
- *   3. emit       tokens of the path positions in [entry, parse_hi); all-gather the counts;
+ *   1. begin      links, match table, restart steps of the buffer; the range is parsed by speculation (its first
+ *                 segment, like every other, finds its entry by a run-up of 128 positions into the history)
+ *   2. spec       did the chain of segment entries and exits inside the range hold, where was the range entered and
+ *                 left?  all-gather: if every rank's entry is the exit of the rank before it (rank 0: position 0),
+ *                 every entry is the true one, the tokens of step 3 are there already and step 2b is not needed
+ *   2b. exit_table X[e] = where the parse leaves the range (offset beyond parse_hi) if it enters at
+ *                 parse_lo + e (made when asked for: the exact way, for periodic data);  all-gather, then every
+ *                 rank knows its entry position
+ *   3. emit       tokens of the path positions in [entry, parse_hi) (returns at once with the speculation's tokens
+ *                 if entry is where that entered); all-gather the counts;
  *                 rank r sends the first (-first_token_index mod 31744) of its tokens to rank r-1
  *   4. blocks     histogram + Huffman per owned block -> cost records; all-gather
  *   5. mi355_plan_blocks (host, every rank, identical result) -> block types and global bit offsets
@@ -218,6 +224,9 @@ typedef struct {
 int mi355_shard_begin(mi355_deflate_ctx* ctx, const void* d_ext, size_t n_ext, size_t parse_lo, size_t parse_hi,
                       uint64_t global_lo, uint64_t n_global, const mi355_deflate_opts* opts, void* hip_stream,
                       mi355_shard** out);
+/* held != 0: the range was parsed from *entry to *exit_pos (buffer coordinates, *exit_pos >= parse_hi), consistently
+ * inside; 0: the caller takes the exact way (exit_table, emit). */
+int mi355_shard_spec(mi355_shard* s, int* held, uint64_t* entry, uint64_t* exit_pos);
 int mi355_shard_exit_table(mi355_shard* s, uint32_t* table576);
 int mi355_shard_emit(mi355_shard* s, uint64_t entry, uint64_t* n_tokens, const void** d_tokens);
 int mi355_shard_blocks(mi355_shard* s, uint64_t skip_tokens, const void* d_tail_tokens, uint64_t n_tail,

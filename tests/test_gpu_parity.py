@@ -407,6 +407,57 @@ def test_p1_sharded_stream_exact(da, world):
             c.close()
 
 
+def test_p1_sharded_ranges_enter_by_speculation(da):
+    """A rank's range finds its entry like a segment does -- a run-up into its history -- and the driver checks that every
+    rank was entered where the rank before it was left (shard.p1_spec_entries): text takes that way and no exit table is
+    made; zero fill (a 258-byte match after the other: paths never meet) does not, and the exit tables decide.  Either
+    way the entries are those of the exact way."""
+    import shard
+    import torch
+    world = 4
+    ctxs = [da.Context(0) for _ in range(world)]
+    try:
+        for name, data, want_chain in (("text", datagen.text_like(6_000_000, 0x51), True),
+                                       ("mixed", datagen.mixed(5_000_000, 0x52), None),   # (its periodic pieces: either way)
+                                       ("zeros", bytes(5_000_000), False)):
+            lay = [shard.p1_layout(len(data), r, world) for r in range(world)]
+            bufs, shards = [], []
+            for r in range(world):
+                L = lay[r]
+                t = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).to("cuda:0")
+                bufs.append(t)
+                shards.append(da.Shard(ctxs[r], t.data_ptr(), L["g_hi"] - L["g_lo"], L["lo"], L["hi"], L["g_lo"], len(data),
+                                       da.Compression.Default, 1))
+            try:
+                specs = [s.spec() for s in shards]
+                fast = shard.p1_spec_entries(lay, specs)
+                exact = shard.p1_entries(lay, [s.exit_table() for s in shards])
+                assert want_chain is None or (fast is not None) == want_chain, (name, specs)
+                if fast is not None:
+                    assert fast == exact, name
+                    # the tokens are there: emit at the speculation's entry hands them out; emit anywhere else takes the exact
+                    # way (exit tables, way down, k_emit<0>) -- and coming back to the true entry afterwards does so too
+                    for r in range(world):
+                        n1, p1 = shards[r].emit(fast[r] - lay[r]["g_lo"])
+                        spec_tok = torch.empty(n1, dtype=torch.int32, device="cuda:0")
+                        shard.ctypes_copy_d2d(spec_tok.data_ptr(), p1, 4 * n1)
+                        shards[r].emit(fast[r] - lay[r]["g_lo"] + 1 if r else 1)
+                        assert not shards[r].spec()[0]
+                        n2, p2 = shards[r].emit(fast[r] - lay[r]["g_lo"])
+                        exact_tok = torch.empty(n2, dtype=torch.int32, device="cuda:0")
+                        shard.ctypes_copy_d2d(exact_tok.data_ptr(), p2, 4 * n2)
+                        assert n1 == n2 and torch.equal(spec_tok, exact_tok), (name, r)
+            finally:
+                for s in shards:
+                    s.close()
+            got = shard.encode_p1_virtual(da, ctxs, data, da.Compression.Default, compat=1)
+            c, l, m = LV["default"]
+            assert got == ob.encode(data, opts=ob.make_opts(c, l, m)), name
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_p1_sharded_ranges_shorter_than_a_block(da):
     """Ranges that yield fewer tokens than it takes to reach the next block boundary own no block: their tokens
     go to a block that began several ranks to the left, and that block's owner takes its tail from the heads of
