@@ -926,6 +926,50 @@ def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
             assert held < 42_000_000, held
 
 
+def test_flushed_stream_is_bounded_between_flushes(da, ctx, small_ranges):
+    """What is written after a flush() is handed over in ranges as well: the first range begins AT the flush point (anywhere in
+    a window, the parse entering exactly there, the blocks counting from there) with the hash quirks of the write calls around
+    the flush -- a 1-byte write after it leaves a position out of the chains and files two a byte late (lz77.rs:601-614) -- and
+    the handle holds a range and its margin, not what has gathered since the flush (the reference: O(window) whatever the
+    flush pattern, compress.rs:96-124).  Bytes of the oracle driven with the same calls."""
+    import io
+    import random
+    data = datagen.text_like(60_000_000, 0x71) + datagen.mixed(30_000_000, 0x72) + datagen.text_like(45_000_000, 0x73)
+    L = da.load()
+    flushes = [7_000_123, 7_000_125, 62_345_679, 62_400_000]  # (two of them two bytes / a few KB apart)
+    for wrapper, cls, lv, first_after in ((0, da.DeflateEncoder, "default", 1), (1, da.ZlibEncoder, "default", 70_001),
+                                          (2, da.GzEncoder, "fast", 1), (0, da.DeflateEncoder, "best", 2)):
+        c, l, m = LV[lv]
+        rnd = random.Random(wrapper + first_after)
+        enc = cls(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+        ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+        if wrapper == 2:
+            ref.gzip_header(da.BLANK_GZIP_HEADER)
+        pos, held, after = 0, 0, False
+        todo = list(flushes)
+        while pos < len(data):
+            step = first_after if after else rnd.choice([5000, 65_536, 1_000_003, 3_500_000])
+            after = False
+            if todo and pos < todo[0] <= pos + step:
+                step = todo[0] - pos
+            step = min(step, len(data) - pos)
+            enc.write_all(data[pos:pos + step])
+            ref.write_all(data[pos:pos + step])
+            pos += step
+            held = max(held, L.mi355_deflate_stream_held_bytes(enc._s))
+            if todo and pos == todo[0]:
+                todo.pop(0)
+                enc.flush()
+                ref.flush()
+                assert enc._w.getvalue().endswith(b"\x00\x00\xff\xff")
+                after = True
+        got = enc.finish().getvalue()
+        want = ref.finish()
+        assert got == want, (wrapper, lv, first_after, len(got), len(want))
+        # range 16 MiB + margin 16 MiB + look-ahead + window + the largest write -- not the 55 MB / 72 MB between the flushes
+        assert held < 42_000_000, held
+
+
 def test_stream_beyond_4gib_without_flush(da, ctx):
     """A ZlibEncoder fed 4.25 GiB (64 MiB of web text, 68 times over) and never flushed: positions beyond 2^32, 512 MiB
     ranges handed over as they fill, the handle holds a range and its margin, not the stream; the stream inflates to

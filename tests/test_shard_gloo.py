@@ -113,6 +113,16 @@ def test_p1_exchange_math():
     lays = [dict(a=0, b=1000), dict(a=1000, b=1200), dict(a=1200, b=3000)]
     tabs = [[300] * shard.ZONE, [7] * shard.ZONE, [0] * shard.ZONE]
     assert shard.p1_entries(lays, tabs) == [0, 1300, 1300]
+    # entries by speculation: every rank reports (held, entry, exit) in its own buffer coordinates; the chain holds iff rank 0
+    # was entered at 0 and every other rank where the rank before it was left -- anything else hands over to the exit tables
+    lays = [dict(a=0, b=65536, g_lo=0), dict(a=65536, b=131072, g_lo=32768), dict(a=131072, b=200000, g_lo=98304)]
+    good = [(True, 0, 65540), (True, 65540 - 32768, 131075 - 32768), (True, 131075 - 98304, 200000 - 98304)]
+    assert shard.p1_spec_entries(lays, good) == [0, 65540, 131075]
+    assert shard.p1_spec_entries(lays, [good[0], (False, 0, 0), good[2]]) is None          # a rank's own chain failed
+    assert shard.p1_spec_entries(lays, [good[0], (True, 65541 - 32768, good[1][2]), good[2]]) is None  # entered elsewhere
+    assert shard.p1_spec_entries(lays, [(True, 3, 65540), good[1], good[2]]) is None       # rank 0 not entered at 0
+    # (a range jumped over: entered and left at the same position behind its end)
+    assert shard.p1_spec_entries(lays[:2], [(True, 0, 131080), (True, 131080 - 32768, 131080 - 32768)]) == [0, 131080]
     # layouts cover the input with history and look-ahead clipped to it
     for total in (5_000_000, 40_000_001):
         for world in (1, 3, 8):
