@@ -29,9 +29,11 @@ extern "C" {
 #define MI355_E_ARG (-1)           /* null pointer / bad option */
 #define MI355_E_OUT_TOO_SMALL (-2) /* *out_len holds the size needed */
 #define MI355_E_HIP (-3)           /* HIP runtime error; see mi355_deflate_last_error */
-#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching; a sync-flush chunk
-                                      (MI355_FLUSH_SYNC) of 4 GiB - 64 KiB or more in one call; 4 GiB - 64 KiB or more
-                                      written since the last flush() of a stream that has been flushed before */
+#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching; 4 GiB - 64 KiB or more
+                                      written behind a flush() that came within the first 96 KiB of a stream (the start of
+                                      a stream has hash rules of its own and is encoded in one pass; everything else --
+                                      one-shot calls, sync-flush chunks, streams flushed or not -- takes any length in
+                                      ranges, in bounded memory) */
 #define MI355_E_REF_PANIC (-5)     /* the reference itself panics on this input (A.4 Q13, slice out
                                       of range) and MI355_COMPAT_Q13 was requested */
 #define MI355_E_STATE (-6)         /* stream used after finish, or after a range of it failed; context busy with a shard */
@@ -108,7 +110,7 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 
 /* Tuning of one context (ctx may be NULL: the default context).  No reference item: the reference has no tunables
  * beyond CompressionOptions; these set the memory / throughput trade of the GPU path, never the bytes it produces.
- *   MI355_CFG_RANGE_BYTES  bytes per range of a long input or never-flushed stream (default 512 MiB; at least 16 MiB,
+ *   MI355_CFG_RANGE_BYTES  bytes per range of a long input or a stream (default 512 MiB; at least 16 MiB,
  *                          at most 3 GiB, rounded down to a multiple of 32768).  Device memory of a long encode is two
  *                          workspaces of about 20 B per byte of a range, host memory of a stream one range + 16 MiB.
  *   MI355_CFG_LONG_FROM    one-shot inputs of at least this many bytes are walked in ranges (default 1 GiB + 1; at most
@@ -321,13 +323,15 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  * encodes at flush() and finish(), and the bytes of a flush -- ending in 00 00 FF FF, as
  * src/writer.rs:570-595 asserts -- are available when flush() returns.  Between flushes the handle keeps
  * the bytes since the last flush plus the 32 KiB window before it (the whole stream while the flushed part
- * is shorter than three windows).  A stream that has NOT been flushed yet is bounded all the same (the
- * reference's O(window) streaming, src/compress.rs:96-124): whenever 512 MiB and a margin of 16 MiB have
- * gathered, write() encodes that range and makes its bytes available (_output / _take_output), keeping the
- * rest, one window of history and the bytes not yet taken -- a stream of any length, e.g. 8 GiB into a
- * ZlibEncoder without a single flush(), holds about 0.55 GiB of host memory.  A flush() of such a stream ends
- * the ranges with the sync marker and the stream goes on as a flushed one; after a flush, what is written
- * until the next flush() / finish() is encoded in one call and must stay below 4 GiB - 64 KiB
+ * is shorter than three windows).  What gathers is bounded all the same (the reference's O(window) streaming,
+ * src/compress.rs:96-124): whenever 512 MiB and a margin of 16 MiB have gathered -- since the start of a stream that
+ * has not been flushed yet, or since the last flush point -- write() encodes that range and makes its bytes available
+ * (_output / _take_output), keeping the rest, one window of history and the bytes not yet taken: a stream of any
+ * length, e.g. 8 GiB into a ZlibEncoder with or without a flush() in the middle, holds about 0.55 GiB of host memory.
+ * The first range behind a flush point begins AT it, with the hash side effects of the write calls around the flush;
+ * the next flush() / finish() ends the last range (with the sync marker / the final block).  The one exception: behind
+ * a flush() within the first 96 KiB of a stream (where a stream's start has hash rules of its own, src/lz77.rs:601-638)
+ * what is written until the next flush() / finish() is encoded in one call and must stay below 4 GiB - 64 KiB
  * (MI355_E_UNSUPPORTED from _write otherwise).  One _write call stands for one write_all call (n == 0: no call at all);
  * the size of the first write after a flush is remembered, because the reference's hash re-warm at a
  * flush point inside the first window depends on it (src/lz77.rs:601-638).  The shim's Drop calls _finish

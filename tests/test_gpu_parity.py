@@ -885,6 +885,24 @@ def test_long_input_walked_in_ranges(da, ctx, small_ranges):
             d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
             n = ctx.encode_device(d_in.data_ptr(), len(data), d_out.data_ptr(), cap, da.CompressionOptions(c, l, m))
             assert bytes(d_out[:n].cpu().numpy()) == ob.encode(data, opts=ob.make_opts(c, l, m, 0)), (name, lv, "device")
+            if lv == "default":
+                # a sync-flush chunk goes through ranges as well (what a fresh encoder has written after write_all + flush():
+                # header, every block non-final, the marker 00 00 FF FF, no trailer), host and device buffers
+                for wrapper in (0, 1):
+                    ref = ob.Stream(ob.make_opts(c, l, m, wrapper))
+                    ref.write_all(data)
+                    ref.flush()
+                    want = ref.output()
+                    got = ctx.encode(data, da.CompressionOptions(c, l, m), wrapper=wrapper, flush=da.FLUSH_SYNC)
+                    assert got == want and got.endswith(b"\x00\x00\xff\xff"), (name, "sync chunk", wrapper, len(got), len(want))
+                    assert ctx.info()["passes"] >= 2
+                d_out.zero_()
+                n = ctx.encode_device(d_in.data_ptr(), len(data), d_out.data_ptr(), cap, da.CompressionOptions(c, l, m),
+                                      flush=da.FLUSH_SYNC)
+                ref = ob.Stream(ob.make_opts(c, l, m, 0))
+                ref.write_all(data)
+                ref.flush()
+                assert bytes(d_out[:n].cpu().numpy()) == ref.output(), (name, "sync chunk on the device")
 
 
 def test_never_flushed_stream_is_bounded(da, ctx, small_ranges):
