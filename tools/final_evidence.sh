@@ -9,3 +9,6 @@ timeout 600 python bench.py > gpurun_out/${TAG}_bench_default_run.json 2> gpurun
 timeout 300 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1; cat gpurun_out/${TAG}_latency.txt
 timeout 300 python tools/kernel_stats.py match > gpurun_out/${TAG}_k_match3_clock_shares.txt 2>&1; cat gpurun_out/${TAG}_k_match3_clock_shares.txt
 timeout 300 python tools/kernel_stats.py sort > gpurun_out/${TAG}_k_sort_clock_shares.txt 2>&1; cat gpurun_out/${TAG}_k_sort_clock_shares.txt
+# the multi-GPU call on this one device (dry run: the ranks' kernels queue on one GPU; what it shows is the host side of the exchanges)
+for n in 2 4 8; do timeout 300 python bench.py --gpus $n --single-process --virtual --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_multi_virtual_N$n.json; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_multi_virtual_N$n.json')); print($n, d['value'], d['ms_per_step'], d.get('multi_trace_ms'))"; done
