@@ -588,7 +588,7 @@ def test_multi_gpu_encode_device_resident(da):
             m.close()
 
 
-def _p1_dist_worker(rank, world, port, q):
+def _p1_dist_worker(rank, world, port, q, backend="gloo"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd"))
@@ -598,21 +598,25 @@ def _p1_dist_worker(rank, world, port, q):
     import shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    data = dg.text_like(6_000_000, 77)  # every rank regenerates the same input and keeps its slice
-    total = len(data)
-    L = shard.p1_layout(total, rank, world)
-    d_ext = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).cuda()
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = da.Context(0)
     ok = []
-    for wrapper in (0, 1, 2):  # raw; zlib and gzip: every rank sums its own range, rank 0 folds and frames
-        out, n = shard.encode_p1_dist(da, ctx, d_ext, L, total, rank, world, da.Compression.Default, compat=1,
-                                      comm_device="cpu", wrapper=wrapper)
-        if rank == 0:
-            import oracle_binding as ob2
-            ref = (ob2.encode_gzip(data, da.BLANK_GZIP_HEADER, level=ob2.DEFAULT) if wrapper == 2
-                   else ob2.encode(data, level=ob2.DEFAULT, wrapper=wrapper))
-            ok.append((wrapper, bytes(out.cpu().numpy()) == ref, n, len(ref)))
+    # text: every rank's range is entered by speculation where the rank before it was left (round 0 of the driver decides);
+    # zero fill in front of text: the chain does not hold and the exit tables are exchanged (round 1)
+    for data in (dg.text_like(6_000_000, 77), bytes(3_500_000) + dg.text_like(2_500_000, 78)):
+        total = len(data)  # every rank regenerates the same input and keeps its slice
+        L = shard.p1_layout(total, rank, world)
+        d_ext = torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(16), dtype=torch.uint8).cuda()
+        for wrapper in (0, 1, 2):  # raw; zlib and gzip: every rank sums its own range, rank 0 folds and frames
+            out, n = shard.encode_p1_dist(da, ctx, d_ext, L, total, rank, world, da.Compression.Default, compat=1,
+                                          comm_device="cpu" if backend == "gloo" else None, wrapper=wrapper)
+            if rank == 0:
+                import oracle_binding as ob2
+                ref = (ob2.encode_gzip(data, da.BLANK_GZIP_HEADER, level=ob2.DEFAULT) if wrapper == 2
+                       else ob2.encode(data, level=ob2.DEFAULT, wrapper=wrapper))
+                ok.append((wrapper, bytes(out.cpu().numpy()) == ref, n, len(ref)))
     if rank == 0:
         q.put(ok)
     dist.barrier()
@@ -634,7 +638,23 @@ def test_p1_distributed_driver_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert [x[:2] for x in ok] == [(0, True), (1, True), (2, True)] and all(x[2] == x[3] for x in ok), ok
+    assert [x[:2] for x in ok] == [(0, True), (1, True), (2, True)] * 2 and all(x[2] == x[3] for x in ok), ok
+
+
+# The same driver over the backend a multi-GPU node uses -- "nccl" (= RCCL) with the exchanged tensors on the device -- as far
+# as ONE GPU can take it: a world of one rank.  Every collective of the driver (all_gather_into_tensor of int64 / int32 / uint8
+# device tensors) goes through RCCL; the point-to-point stitch has no peer here and is covered by the gloo run above.
+def test_p1_distributed_driver_rccl_world_of_one():
+    import torch.multiprocessing as mp
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    p = mctx.Process(target=_p1_dist_worker, args=(0, 1, port, q, "nccl"))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert [x[:2] for x in ok] == [(0, True), (1, True), (2, True)] * 2 and all(x[2] == x[3] for x in ok), ok
 
 
 # flush() = Flush::Sync with window retention (writer.rs:134-137, 571-660; tests/test.rs:113-123
