@@ -1008,6 +1008,47 @@ def test_flushed_stream_is_bounded_between_flushes(da, ctx, small_ranges):
         assert held < 42_000_000, held
 
 
+def test_flushed_stream_behind_an_early_flush(da, ctx, small_ranges):
+    """The same behind a flush point inside the first three windows, where a stream's start has rules of its own: the range that
+    begins there holds the stream from its start and takes over what the flush calls of the stream passed to the single pass --
+    the flush points that re-warm the hash, the Q1 re-warm a flush call found (noise at the start: block 0 fills inside the
+    first window) -- or finds Q1 itself when the block that fills inside the first window begins at the flush point."""
+    import io
+    L = da.load()
+    noise_head = datagen.rng_bytes(70_000, 0x81) + datagen.text_like(44_000_000, 0x82)
+    text = datagen.text_like(41_000_000, 0x83)
+    cases = [(noise_head, [5], 1, "default"),          # Q1 is found by the range (its block 0 begins at the flush point)
+             (noise_head, [65_537], 2, "default"),     # Q1 was found by the flush call, the re-warmed hashes are still in the window
+             (noise_head, [40_000, 40_002], 1, "fast"),
+             (text, [20_000], 1, "default"),           # a flush point that re-warms the hash, a 1-byte write behind it
+             (text, [2, 3], 70_001, "best"),
+             (text, [98_303], 1, "default")]
+    for data, flushes, first_after, lv in cases:
+        c, l, m = LV[lv]
+        enc = da.ZlibEncoder(io.BytesIO(), da.CompressionOptions(c, l, m), ctx)
+        ref = ob.Stream(ob.make_opts(c, l, m, 1))
+        pos, held, after, todo = 0, 0, False, list(flushes)
+        while pos < len(data):
+            step = first_after if after else 3_000_000
+            after = False
+            if todo and pos < todo[0] <= pos + step:
+                step = todo[0] - pos
+            step = min(step, len(data) - pos)
+            enc.write_all(data[pos:pos + step])
+            ref.write_all(data[pos:pos + step])
+            pos += step
+            held = max(held, L.mi355_deflate_stream_held_bytes(enc._s))
+            if todo and pos == todo[0]:
+                todo.pop(0)
+                enc.flush()
+                ref.flush()
+                after = True
+        got = enc.finish().getvalue()
+        want = ref.finish()
+        assert got == want, (flushes, first_after, lv, len(got), len(want))
+        assert held < 40_000_000, held  # (not the 41-44 MB behind the flush)
+
+
 def test_stream_beyond_4gib_without_flush(da, ctx):
     """A ZlibEncoder fed 4.25 GiB (64 MiB of web text, 68 times over) and never flushed: positions beyond 2^32, 512 MiB
     ranges handed over as they fill, the handle holds a range and its margin, not the stream; the stream inflates to

@@ -2,7 +2,8 @@
 (16 MiB ranges): random flush points -- inside the first three windows (such a chunk is one pass), at and around window
 edges, anywhere -- with 1-byte, 2-byte and longer first writes behind them and flushes a few bytes apart, every level and
 framing, against the oracle driven with the same calls.
-usage: fuzz_flushed_ranges.py [cases] [first_seed]"""
+usage: fuzz_flushed_ranges.py [cases] [first_seed] [early]   (early: every case has a chunk of 40 MB or more right behind a flush
+point inside the first windows of the stream, where Q1 and the hash re-warm at flush points apply)"""
 import io, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +16,7 @@ LV = {"fast": (1, 0, 0), "default": (128, 32, 1), "best": (1768, 128, 1), "rle":
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    early = len(sys.argv) > 3  # every case: a long chunk right behind a flush point inside the first windows
     ctx = da.Context(0)
     ctx.config(ctx.CFG_RANGE_BYTES, 16 << 20)
     L = da.load()
@@ -25,10 +27,22 @@ def main():
         n = rnd.randrange(60_000_000, len(pool))
         off = rnd.randrange(0, len(pool) - n + 1)
         data = pool[off:off + n]
+        if rnd.random() < 0.45:  # noise at the stream's start: a block that fills inside the first window (Q1), stored blocks
+            k = rnd.choice([20_000, 40_000, 70_000, 200_000])
+            data = datagen.rng_bytes(k, seed) + data[k:]
         edge = rnd.choice([0, 1, 2, 32767, 32768, 32769, 98303, 98304, 98305, 12345])
-        points = sorted(set([rnd.choice([5, 40_000, 90_000, 98_304 + edge, rnd.randrange(200_000, 20_000_000) // 32768 * 32768 + edge]),
-                             rnd.randrange(1_000_000, n - 40_000_000)] +
-                            ([rnd.randrange(1_000_000, n)] if rnd.random() < 0.5 else [])))
+        if early:
+            first_pt = rnd.choice([1, 2, 3, 5, 300, 20_000, 31_000, 32_767, 32_768, 33_000, 40_000, 65_535, 65_536, 65_537, 70_000, 90_000, 98_303])
+            points = [first_pt]
+        else:
+            points = [rnd.choice([1, 2, 5, 20_000, 31_000, 33_000, 40_000, 65_536, 65_537, 90_000, 98_304 + edge,
+                                  rnd.randrange(200_000, 20_000_000) // 32768 * 32768 + edge]),
+                      rnd.randrange(1_000_000, n - 40_000_000)]
+        if rnd.random() < 0.5:
+            points.append(rnd.randrange(1_000_000, n))
+        points = sorted(set(points))
+        if early:  # an early flush point (or two of them close together) and nothing else before a chunk of at least 40 MB
+            points = [points[0]] + [p for p in points[1:] if p > points[0] + 40_000_000]
         if rnd.random() < 0.5:  # a second flush a few bytes behind one of them
             q = rnd.choice(points)
             points = sorted(set(points + [q + rnd.choice([1, 2, 3, 700])]))
