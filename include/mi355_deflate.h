@@ -29,11 +29,9 @@ extern "C" {
 #define MI355_E_ARG (-1)           /* null pointer / bad option */
 #define MI355_E_OUT_TOO_SMALL (-2) /* *out_len holds the size needed */
 #define MI355_E_HIP (-3)           /* HIP runtime error; see mi355_deflate_last_error */
-#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching; 4 GiB - 64 KiB or more
-                                      written behind a flush() that came within the first 96 KiB of a stream (the start of
-                                      a stream has hash rules of its own and is encoded in one pass; everything else --
-                                      one-shot calls, sync-flush chunks, streams flushed or not -- takes any length in
-                                      ranges, in bounded memory) */
+#define MI355_E_UNSUPPORTED (-4)   /* lazy_if_less_than < 3 with Lazy matching -- nothing else: one-shot
+                                      calls, sync-flush chunks and streams, flushed anywhere or not at all, take any length
+                                      in ranges, in bounded memory */
 #define MI355_E_REF_PANIC (-5)     /* the reference itself panics on this input (A.4 Q13, slice out
                                       of range) and MI355_COMPAT_Q13 was requested */
 #define MI355_E_STATE (-6)         /* stream used after finish, or after a range of it failed; context busy with a shard */
@@ -329,10 +327,10 @@ int mi355_adler32_device(mi355_deflate_ctx* ctx, const void* d_in, size_t in_len
  * (_output / _take_output), keeping the rest, one window of history and the bytes not yet taken: a stream of any
  * length, e.g. 8 GiB into a ZlibEncoder with or without a flush() in the middle, holds about 0.55 GiB of host memory.
  * The first range behind a flush point begins AT it, with the hash side effects of the write calls around the flush;
- * the next flush() / finish() ends the last range (with the sync marker / the final block).  The one exception: behind
- * a flush() within the first 96 KiB of a stream (where a stream's start has hash rules of its own, src/lz77.rs:601-638)
- * what is written until the next flush() / finish() is encoded in one call and must stay below 4 GiB - 64 KiB
- * (MI355_E_UNSUPPORTED from _write otherwise).  One _write call stands for one write_all call (n == 0: no call at all);
+ * the next flush() / finish() ends the last range (with the sync marker / the final block).  Behind a flush() within the
+ * first 96 KiB of a stream -- where a stream's start has hash rules of its own, src/lz77.rs:601-638 -- the first range
+ * holds the stream from its start and takes over what the flush calls found: the flush points that re-warm the hash and
+ * the re-warm behind a block that fills inside the first window (Q1).  One _write call stands for one write_all call (n == 0: no call at all);
  * the size of the first write after a flush is remembered, because the reference's hash re-warm at a
  * flush point inside the first window depends on it (src/lz77.rs:601-638).  The shim's Drop calls _finish
  * and drains the output like the reference's (src/writer.rs:139-152). */

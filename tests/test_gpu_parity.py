@@ -1015,11 +1015,21 @@ def test_flushed_stream_behind_an_early_flush(da, ctx, small_ranges):
     first window) -- or finds Q1 itself when the block that fills inside the first window begins at the flush point."""
     import io
     L = da.load()
-    noise_head = datagen.rng_bytes(70_000, 0x81) + datagen.text_like(44_000_000, 0x82)
     text = datagen.text_like(41_000_000, 0x83)
-    cases = [(noise_head, [5], 1, "default"),          # Q1 is found by the range (its block 0 begins at the flush point)
-             (noise_head, [65_537], 2, "default"),     # Q1 was found by the flush call, the re-warmed hashes are still in the window
-             (noise_head, [40_000, 40_002], 1, "fast"),
+    # Input on which Q1 SHOWS: noise whose first 31 744 tokens end inside the first window (the re-warm files the two positions
+    # behind that block under hashes of the stream's first two bytes), then a short copy of the noise at every position from
+    # 31 700 to 32 100, each behind a separator: the copy of a re-warmed position finds no candidate there (the oracle: a match
+    # of 7 at distance 8 into the copy before it instead of 8 at the distance of the noise -- checked with tools/tokdump.py).
+    noise = datagen.rng_bytes(33_000, 0x91)
+    seps = datagen.rng_bytes(400, 0x92)
+    copies = b"".join(noise[k:k + 8] + seps[k - 31_700:k - 31_699] for k in range(31_700, 32_100))
+    q1_early = noise[:32_200] + copies + text      # flush at 5: the block that fills inside the first window begins there
+    q1_given = noise + copies + text               # flush at 33 000: a flush call has found Q1, the copies come behind the flush
+    cases = [(q1_early, [5], 1, "default"),
+             (q1_early, [5], 2, "best"),
+             (q1_given, [33_000], 1, "default"),
+             (q1_given, [33_000], 70_000, "fast"),
+             (q1_given, [40_000, 40_002], 1, "fast"),
              (text, [20_000], 1, "default"),           # a flush point that re-warms the hash, a 1-byte write behind it
              (text, [2, 3], 70_001, "best"),
              (text, [98_303], 1, "default")]
