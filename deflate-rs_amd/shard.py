@@ -229,11 +229,12 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
     calls (nothing of stream size is allocated or cleared per step): it is valid until the next call on this process --
     clone it to keep it.
 
-    What travels, four rounds: (1) all-gather of the 576-entry exit tables, (2) all-gather
-    of the token counts while the up to 31 743 head tokens go to the left neighbour, (3) ONE all-gather of a
-    fixed-size record per rank -- block count, checksum, block costs -- after which every rank runs the same
-    serial plan and knows every rank's byte range, (4) the byte ranges to rank 0, whose receives are posted
-    before it packs its own blocks."""
+    What travels, three rounds: (1) ONE all-gather of a record per rank -- "my speculative parse held,
+    entered at, left at", the token count and the up to 31 743 head tokens (if the ranks' chain of entries and exits does not
+    hold -- periodic data -- the 576-entry exit tables are gathered, the tokens made from the true entries and this round
+    repeated), (2) ONE all-gather of a fixed-size record per rank -- block count, checksum, block costs -- after which every
+    rank runs the same serial plan and knows every rank's byte range, (3) the byte ranges to rank 0, whose receives are
+    posted before it packs its own blocks."""
     import ctypes
     import os
     import time
@@ -258,40 +259,46 @@ def encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options=None, com
                   torch.cuda.current_stream(dev).cuda_stream)
     mark("chains, match table, speculative parse")
     lays = [p1_layout(total, r, world) for r in range(world)]
-    # round 0: did every rank's speculative parse hold, and do the ranks' entries and exits form one chain?  Then the tokens
-    # are there and no exit table is made (every rank decides the same from the same numbers)
+    # round 0 + 2 in one gather: a rank's record is [token count, "my speculative parse held, entered at, left at", the head of
+    # its tokens] -- the count and the head are those of the speculation's tokens, which are the tokens iff every rank's chain
+    # held and every rank was entered where the rank before it was left (every rank decides the same from the same numbers).
+    # (A rank may need up to 31 743 tokens from its right to complete its last block -- from the next rank, or from several
+    # when their ranges are short: hence the heads.)
+    HDR = 8
+
+    def gather_counts(n_tok, tok_ptr, held, e_in, e_out):
+        head_n = min(n_tok, BLOCK_TOKENS - 1)
+        rec2 = torch.zeros(HDR + BLOCK_TOKENS - 1, dtype=torch.int32, device=dev)
+        if head_n:
+            ctypes_copy_d2d(rec2.data_ptr() + 4 * HDR, tok_ptr, head_n * 4)
+        rec2[:HDR] = torch.tensor([n_tok & 0x7FFFFFFF, n_tok >> 31, int(held), e_in & 0x7FFFFFFF, e_in >> 31,
+                                   e_out & 0x7FFFFFFF, e_out >> 31, 0], dtype=torch.int32)
+        allr2 = torch.empty(world * rec2.numel(), dtype=torch.int32, device=cdev)
+        dist.all_gather_into_tensor(allr2, rec2.to(cdev), group=group)
+        allr2 = allr2.view(world, rec2.numel())
+        return allr2, allr2[:, :HDR].tolist()
+
     held, e_in, e_out = sh.spec()
-    mine0 = torch.tensor([int(held), e_in, e_out], dtype=torch.int64, device=cdev)
-    all0 = torch.empty(world * 3, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(all0, mine0, group=group)
-    entries = p1_spec_entries(lays, [(bool(h), e, x) for h, e, x in all0.view(world, 3).tolist()])
-    mark("x0 entries and exits")
+    n_tok, tok_ptr = sh.emit(e_in) if held else (0, 0)  # (returns at once: the speculation's tokens)
+    all2, hdrs2 = gather_counts(n_tok, tok_ptr, held, e_in, e_out)
+    entries = p1_spec_entries(lays, [(bool(h[2]), h[3] | (h[4] << 31), h[5] | (h[6] << 31)) for h in hdrs2])
+    mark("x0 counts, entries and exits, straddling tokens")
     if entries is None:
-        # round 1: exit tables -> entry positions
+        # (periodic data: the exact way) round 1: exit tables -> entry positions; the tokens from there; round 2 again
         mine = torch.tensor(sh.exit_table(), dtype=torch.int32, device=cdev)
         allv = torch.empty(world * ZONE, dtype=torch.int32, device=cdev)
         dist.all_gather_into_tensor(allv, mine, group=group)
         tables = allv.view(world, ZONE).tolist()
         entries = p1_entries(lays, tables)
         mark("x1 exit tables")
-    n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
-    mark("emit")
-    # round 2: token counts and the head of every rank's tokens (a rank may need up to 31 743 tokens from its right
-    # to complete its last block -- from the next rank, or from several when their ranges are short): one gather
-    head_n = min(n_tok, BLOCK_TOKENS - 1)
-    rec2 = torch.zeros(BLOCK_TOKENS + 1, dtype=torch.int32, device=dev)
-    if head_n:
-        ctypes_copy_d2d(rec2.data_ptr() + 8, tok_ptr, head_n * 4)
-    rec2[:2] = torch.tensor([n_tok & 0x7FFFFFFF, n_tok >> 31], dtype=torch.int32)
-    all2 = torch.empty(world * (BLOCK_TOKENS + 1), dtype=torch.int32, device=cdev)
-    dist.all_gather_into_tensor(all2, rec2.to(cdev), group=group)
-    all2 = all2.view(world, BLOCK_TOKENS + 1)
-    cnts = all2[:, :2].tolist()
-    counts = [int(a) | (int(b) << 31) for a, b in cnts]
+        n_tok, tok_ptr = sh.emit(entries[rank] - L["g_lo"])
+        mark("emit")
+        all2, hdrs2 = gather_counts(n_tok, tok_ptr, False, 0, 0)
+    counts = [int(h[0]) | (int(h[1]) << 31) for h in hdrs2]
     skip, tail, owns, pieces = p1_token_plan(counts)
     tail_t = None
     if tail[rank]:
-        tail_t = torch.cat([all2[q, 2:2 + k] for q, k in pieces[rank]]).to(dev).contiguous()
+        tail_t = torch.cat([all2[q, HDR:HDR + k] for q, k in pieces[rank]]).to(dev).contiguous()
     mark("x2 counts + straddling tokens")
     # this rank's checksum (its own range only), on its GPU -- before the block phase, whose device scalars
     # the pack kernel still reads
