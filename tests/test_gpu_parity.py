@@ -1059,10 +1059,13 @@ def test_flushed_stream_behind_an_early_flush(da, ctx, small_ranges):
         assert held < 40_000_000, held  # (not the 41-44 MB behind the flush)
 
 
-def test_stream_beyond_4gib_without_flush(da, ctx):
+@pytest.mark.parametrize("flush_after", [None, (256 << 20) + 12345])
+def test_stream_beyond_4gib_without_flush(da, ctx, flush_after):
     """A ZlibEncoder fed 4.25 GiB (64 MiB of web text, 68 times over) and never flushed: positions beyond 2^32, 512 MiB
     ranges handed over as they fill, the handle holds a range and its margin, not the stream; the stream inflates to
-    the input (checked piece by piece) and ends in its Adler-32."""
+    the input (checked piece by piece) and ends in its Adler-32.  The same with ONE flush() a quarter GiB in and a 1-byte
+    write behind it: 4 GiB follow the flush point -- more than a single pass takes, refused before round 4 -- in ranges
+    that begin AT the flush point (anywhere in a window), the handle as small as without the flush."""
     import io
     block = datagen.webtext(64 << 20)
     reps = 68
@@ -1088,9 +1091,20 @@ def test_stream_beyond_4gib_without_flush(da, ctx):
     sink = Check()
     enc = da.ZlibEncoder(sink, da.Compression.Default, ctx)
     held = 0
+    written = 0
     for _ in range(reps):
-        for o in range(0, len(block), 32 << 20):
-            enc.write_all(block[o:o + (32 << 20)])
+        o = 0
+        while o < len(block):
+            k = 32 << 20
+            if flush_after is not None and written < flush_after < written + k:
+                k = flush_after - written
+            elif flush_after is not None and written == flush_after:
+                enc.flush()
+                k = 1
+            k = min(k, len(block) - o)
+            enc.write_all(block[o:o + k])
+            o += k
+            written += k
             held = max(held, L.mi355_deflate_stream_held_bytes(enc._s))
     enc.finish()
     assert sink.d.eof and sink.pos == reps * len(block)  # (zlib has checked the Adler-32 of all 4.25 GiB)
