@@ -196,8 +196,8 @@ def single_process(args, da):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random", "silesia", "webtext"])
     ap.add_argument("--size", type=int, default=0, help="bytes per GPU (0 = the config's size)")
     ap.add_argument("--level", default="", choices=["", "default", "best", "fast", "rle", "huffman_only"],
