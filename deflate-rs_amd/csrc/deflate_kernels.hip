@@ -1818,8 +1818,15 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         uint32_t np = 0;
         uint32_t j;
         if (SPEC) {
+            // the run-up: to the first restart position in the segment -- four steps at a time while they stay in front of
+            // it, then single steps (single steps all the way were some twenty dependent LDS reads on one lane)
             j = 0;
-            while (j < w0) j += A[j];  // the run-up: single steps to the first restart position in the segment
+            for (;;) {
+                const uint32_t t = j + P[j];
+                if (t >= w0) break;
+                j = t;
+            }
+            while (j < w0) j += A[j];
             E0[k] = (uint32_t)(a + j);
         } else {
             const uint64_t e = MODE == 2 ? (uint64_t)given : (uint64_t)E0[k];
