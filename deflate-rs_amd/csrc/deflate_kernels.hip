@@ -75,6 +75,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+constexpr uint32_t PIECES_MAX = 12;  // (deflate_host.inc ARRIVE_MAX)
 // scalars shared between kernels of one encode
 struct DevScalars {
     uint32_t T;            // tokens in the stream
@@ -89,8 +90,17 @@ struct DevScalars {
     uint32_t adler;
     uint32_t crc;          // CRC-32 of the input (gzip trailer), XOR-accumulated by k_crc_fold
     uint64_t adler_a, adler_b;  // sums of the chunk contributions (k_adler_part)
-    uint32_t n_fix;        // segments whose speculative entry did not check out (k_spec_check)
-    uint32_t pad_;
+    uint32_t n_fix[PIECES_MAX];    // segments whose speculative entry did not check out (k_spec_check), per piece
+    // A host call whose input is still arriving works on the stream piece by piece (deflate_host.inc run_streamed): what a
+    // piece hands to the next one -- tokens and complete blocks so far; total_bits above is the bit position so far
+    uint32_t Tcum[PIECES_MAX + 1];
+    uint32_t nbcum[PIECES_MAX + 1];
+};
+// which part of the stream a launch of the token / block kernels works on (a whole encode: piece 0 of one, `last`)
+struct Piece {
+    uint32_t seg_lo;  // its first segment; its last is the kernel's K
+    uint32_t p;       // its number
+    uint32_t last;    // the stream ends with it
 };
 
 // ... and what outlives the clearing of the scalars at the start of an encode
@@ -1752,7 +1762,7 @@ constexpr uint32_t FIX_HOPS = 24;
 struct SpecFix {
     uint32_t* list;          // segments whose entry is not the exit of the segment before
     uint32_t* badmap;        // the same as a bit per segment
-    const DevScalars* sc;    // sc->n_fix = how many
+    const uint32_t* n;       // how many
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
@@ -1760,17 +1770,17 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
                                               uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
                                               uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
-                                              uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0) {
+                                              uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0, uint32_t seg0) {
     constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
     __shared__ uint16_t s_adv[4][REG];
     __shared__ uint16_t s_pp[4][REG];
     __shared__ uint32_t s_np[4], s_exit[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint64_t k = (uint64_t)blockIdx.x * 4 + wv;
+    uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
     uint32_t given = 0;  // MODE 2: the entry the segment is parsed from
     if (MODE == 2) {
-        const uint32_t nf = fix.sc->n_fix;
+        const uint32_t nf = *fix.n;
         if (nf > FIX_MAX || k >= nf) return;
         k = fix.list[k];
         given = Xs[k - 1];  // (a listed segment is never the first)
@@ -1918,9 +1928,11 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
 
 // k_spec_check: after the speculative k_emit, which segments were entered somewhere else than the segment before them was
 // left?  A bit per segment and a list (in no particular order) for the repair; sc->n_fix counts them.
+// (lo: the first segment of the range looked at -- a multiple of 64 -- K its end)
 __global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* __restrict__ E0, const uint32_t* __restrict__ Xs,
-                                                    uint32_t* __restrict__ badmap, uint32_t* __restrict__ list, DevScalars* sc) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+                                                    uint32_t* __restrict__ badmap, uint32_t* __restrict__ list, uint32_t* __restrict__ n_fix,
+                                                    uint32_t lo) {
+    const uint32_t i = lo + blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
     const uint64_t m = __builtin_amdgcn_ballot_w64(off);
     if (lane == 0) {
@@ -1929,7 +1941,7 @@ __global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* 
     }
     if (m == 0) return;
     uint32_t at = 0;
-    if (lane == 0) at = atomicAdd(&sc->n_fix, (uint32_t)__popcll(m));
+    if (lane == 0) at = atomicAdd(n_fix, (uint32_t)__popcll(m));
     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     if (off && at + rank < FIX_MAX) list[at + rank] = i;
@@ -1949,10 +1961,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 // (E0 / Xs / spec_bad: after a speculative k_emit -- every segment's entry must be the exit of the segment before it)
 __global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ part,
                                                  const uint32_t* __restrict__ E0, const uint32_t* __restrict__ Xs,
-                                                 uint32_t* __restrict__ spec_bad) {
+                                                 uint32_t* __restrict__ spec_bad, uint32_t lo) {
     __shared__ uint32_t wtot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t i = blockIdx.x * 1024 + tid;
+    const uint32_t i = lo + blockIdx.x * 1024 + tid;
     if (Xs) {
         const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
         const uint64_t offm = __builtin_amdgcn_ballot_w64(off);
@@ -1971,9 +1983,10 @@ __global__ __launch_bounds__(1024) void k_scan_a(uint32_t K, const uint32_t* __r
 }
 // (tend / pb: a one-shot call has one segment, whose token count and block count are the totals -- written here, and
 // k_seg_tokens / k_block_count are not launched)
+// (pc: the segments [pc.seg_lo, K) are one piece of the stream; the tokens before it are sc->Tcum[pc.p])
 __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ part,
                                                  uint32_t* __restrict__ base, DevScalars* sc, uint32_t* __restrict__ tend,
-                                                 uint32_t* __restrict__ pb) {
+                                                 uint32_t* __restrict__ pb, Piece pc) {
     __shared__ uint32_t wtot[16], red[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // sum of the workgroups before this one
@@ -1982,12 +1995,12 @@ __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __r
 #pragma unroll
     for (int off = 32; off; off >>= 1) pre += __shfl_xor(pre, off, 64);
     if (lane == 0) red[wv] = pre;
-    const uint32_t i = blockIdx.x * 1024 + tid;
+    const uint32_t i = pc.seg_lo + blockIdx.x * 1024 + tid;
     const uint32_t v = i < K ? cnt[i] : 0;
     const uint32_t x = wave_incl_scan(v, lane);
     if (lane == 63) wtot[wv] = x;
     __syncthreads();
-    uint32_t add = 0, all = 0;
+    uint32_t add = sc->Tcum[pc.p], all = 0;
     for (uint32_t k = 0; k < 16; k++) {
         add += red[k];
         add += k < wv ? wtot[k] : 0;
@@ -1995,15 +2008,19 @@ __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __r
     }
     if (i < K) base[i] = add + x - v;
     if (tid == 0 && blockIdx.x == gridDim.x - 1) {
-        uint32_t T = 0;
+        uint32_t T = sc->Tcum[pc.p];
         for (uint32_t k = 0; k < 16; k++) T += red[k];
         T += all;
+        // (the blocks that are complete with this piece; the stream's last block may be short or empty)
+        const uint32_t nb = T / MAX_BUFFER_LENGTH + (pc.last ? 1u : 0u);
         sc->T = T;
-        sc->nb = T / MAX_BUFFER_LENGTH + 1;
+        sc->nb = nb;
+        sc->Tcum[pc.p + 1] = T;
+        sc->nbcum[pc.p + 1] = nb;
         if (tend) {
             tend[0] = T;
             pb[0] = 0;
-            pb[1] = T / MAX_BUFFER_LENGTH + 1;
+            pb[1] = nb;
         }
     }
 }
@@ -2017,8 +2034,8 @@ __global__ void k_scan_zero(DevScalars* sc) {
 // k_compact: tokens of all segments into one dense stream.
 __global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __restrict__ tokbuf,
                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
-                                                 uint32_t* __restrict__ dtok, const DevScalars* sc) {
-    uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                 uint32_t* __restrict__ dtok, const DevScalars* sc, uint32_t seg0) {
+    uint64_t k = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + seg0;
     if (k >= K || spec_failed(sc)) return;
     uint32_t lane = threadIdx.x & 63;
     uint32_t c = cnt[k], b = base[k];
@@ -2107,13 +2124,21 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
                                                       const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
                                                       const uint32_t* __restrict__ dtok, DevScalars* sc,
                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13,
-                                                      BlockTab tab) {
-    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                      BlockTab tab, Piece pc, const uint32_t* __restrict__ xs_last) {
+    // (a piece of a stream that is still arriving: the blocks that became complete with it, sc->nbcum[pc.p] .. sc->nb - 1)
+    const uint32_t b = sc->nbcum[pc.p] + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b > nb_max) return;
     const uint32_t nb = sc->nb;
     if (b > nb) return;
     if (b == nb) {
-        if (lane == 0) bstart[b] = n;
+        // where the block behind the last one begins: the end of the data -- or, while the stream goes on, where the first
+        // token that is not in a complete block starts (behind the last token so far if there is none yet: xs_last)
+        uint32_t bs = n;
+        if (!pc.last) {
+            const uint32_t t = nb * (uint32_t)MAX_BUFFER_LENGTH;
+            bs = t < sc->T ? token_start(t, K, base, E0, tokbuf, lane) : *xs_last;
+        }
+        if (lane == 0) bstart[b] = bs;
         return;
     }
     uint32_t lo = 0, hi = sg.m;  // segment i with pb[i] <= b < pb[i+1]
@@ -2189,9 +2214,9 @@ static_assert(MAX_BUFFER_LENGTH % PSPLIT == 0, "parts of equal size");
 
 __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                                     uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq,
-                                                    BlockTab tab) {
+                                                    BlockTab tab, uint32_t piece) {
     __shared__ uint32_t h[320];
-    const uint32_t b = blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
+    const uint32_t b = sc->nbcum[piece] + blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
     if (b >= sc->nb || spec_failed(sc)) return;
     for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
     __syncthreads();
@@ -2403,9 +2428,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
-                                                      const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr) {
+                                                      const uint32_t* __restrict__ d_freq, BlockHeader* __restrict__ hdr, uint32_t piece) {
     __shared__ HdrLds s;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t b = sc->nbcum[piece] + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (b >= sc->nb || spec_failed(sc)) return;
     HT_DECL
     for (uint32_t i = tid; i < 288; i += 128) {
@@ -2552,13 +2577,14 @@ __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint6
 __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
                                              const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
                                              BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
-                                             const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32) {
+                                             const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc) {
     const uint32_t lane = threadIdx.x;
     if (spec_failed(sc)) return;
-    const uint32_t nb = sc->nb;
-    uint64_t bitpos = bit_base;
+    // (a piece: the blocks from sc->nbcum[pc.p] on, behind the bits planned so far; `fin` = the block that ends the stream)
+    const uint32_t nb = sc->nb, fin = pc.last ? nb : 0xFFFFFFFFu;
+    uint64_t bitpos = bit_base + sc->total_bits;
     uint32_t n_st = 0, n_fx = 0, n_dy = 0, hits = 0, panic = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+    for (uint32_t b0 = sc->nbcum[pc.p]; b0 < nb; b0 += 64) {
         uint32_t b = b0 + lane;
         bool have = b < nb;
         uint64_t dyn_bits = 0, dyn_est = 0, static_est = 0, fixed_bits = 0, in_bytes = 0;
@@ -2582,7 +2608,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         p0.bfinal = 0;
         p0.bit_start = 0;
         p0.bit_len = 0;
-        if (have) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb && my_sync == 0, 0, &p0);
+        if (have) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == fin && my_sync == 0, 0, &p0);
         if (fixed_len) {
 #pragma unroll
             for (uint32_t ph = 1; ph < 8; ph++) {
@@ -2596,7 +2622,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
         // byte boundary, so every block but the group's first starts at phase 0 -- the length p0 was computed
         // for -- and the first one takes the real phase.
         if (__builtin_amdgcn_ballot_w64(have && !(fixed_type && p0.btype == BT_STORED)) == 0) {
-            if (lane == 0) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == nb, bitpos, &p0);
+            if (lane == 0) plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == fin, bitpos, &p0);
             const uint64_t mylen = have ? p0.bit_len : 0ull;
             uint64_t incl = mylen;
 #pragma unroll
@@ -2644,7 +2670,7 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
             if (lane == sidx) {
                 BlockPlan p;
                 const bool sync = my_sync != 0;
-                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == nb) && !sync, bitpos, &p);
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, (b + 1 == fin) && !sync, bitpos, &p);
                 plan[b] = p;
                 len = p.bit_len;
                 if (sync) {  // compress.rs:256-261: empty stored block = 3 zero bits, pad, 00 00 FF FF
@@ -2681,11 +2707,11 @@ __global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* 
     }
     if (lane == 0) {
         sc->total_bits = bitpos - bit_base;
-        sc->n_stored = n_st;
-        sc->n_fixed = n_fx;
-        sc->n_dynamic = n_dy;
-        sc->q13_hits = hits;
-        sc->ref_panic = panic;
+        sc->n_stored += n_st;
+        sc->n_fixed += n_fx;
+        sc->n_dynamic += n_dy;
+        sc->q13_hits += hits;
+        sc->ref_panic |= panic;
     }
 }
 
@@ -2745,9 +2771,9 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
                                               const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
                                               uint32_t compat, uint32_t* __restrict__ out32, BlockTab tab,
-                                              const uint32_t* __restrict__ ll_freq, const uint32_t* __restrict__ d_freq) {
+                                              const uint32_t* __restrict__ ll_freq, const uint32_t* __restrict__ d_freq, uint32_t piece) {
     __shared__ PackLds s;
-    const uint32_t b = blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT, tid = threadIdx.x;
+    const uint32_t b = sc->nbcum[piece] + blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT, tid = threadIdx.x;
     if (b >= sc->nb || spec_failed(sc)) return;
     const uint32_t gtid = part * PKT + tid;  // a stored block's bytes are spread over all parts' threads
     constexpr uint32_t GT = PKT * PSPLIT;

@@ -239,7 +239,7 @@ class Context:
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
 
-    CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS = 1, 2, 3
+    CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS, CFG_HOST_STREAMING = 1, 2, 3, 4
 
     def config(self, key, value):
         """mi355_deflate_ctx_config: range size / long-input threshold / where the sort takes its ranks from"""

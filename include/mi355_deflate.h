@@ -117,10 +117,18 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          that passed the self-test of mi355_deflate_ctx_create; MI355_E_UNSUPPORTED on one that did
  *                          not), 0 = ballots (any device; about 40 % more time in the sort).  Whatever the setting, the
  *                          match kernel checks every hash bucket's order on the data it walks and an encode that finds
- *                          one out of order is done again with ballot ranks, which the context then keeps. */
+ *                          one out of order is done again with ballot ranks, which the context then keeps.
+ *   MI355_CFG_HOST_STREAMING  how a host-buffer call of 16 MiB or more (mi355_deflate_encode and its zlib / gzip
+ *                          forms) hands its bytes back: 1 (default) = piece by piece -- the input arrives in pieces, each
+ *                          is encoded as it arrives (its parse, block and pack stages beside the match stage of the next
+ *                          one) and the finished bytes leave on the copy engine while the later pieces are worked on;
+ *                          0 = one copy-out after the last kernel; 2 = pieces with their stages behind each other
+ *                          (a measuring aid).  Same bytes every way; data the piecewise form does not take (a hash re-warm
+ *                          in the first window, long periodic data) is encoded the other way without the caller noticing. */
 #define MI355_CFG_RANGE_BYTES 1
 #define MI355_CFG_LONG_FROM 2
 #define MI355_CFG_SORT_RANKS 3
+#define MI355_CFG_HOST_STREAMING 4
 int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers

@@ -878,6 +878,80 @@ def small_ranges(da, ctx):
     _set_long(ctx, 512 << 20, (1 << 30) + 1)
 
 
+def test_identity_hop_after_first_slide(da, ctx):
+    """tests/golden/identity_hop.bin (gen_identity_hop.py): the first block fills exactly at the end of the first window, so the
+    hash re-warm (Q1, lz77.rs:628-638) files positions 32768 and 32769 under hashes that are not their bytes'; after the first
+    slide the head table's identity entries 0 and 1 (chained_hash_table.rs:197-219) point at exactly those two positions, and
+    the third window begins with a copy of their bytes: position 65536 of the reference finds a match of 64 at distance 32768
+    through an entry no bucket holds.  The GPU path must produce the oracle's stream (the committed digests) -- at every level
+    with a hash, one-shot and as a stream written in two parts."""
+    import hashlib
+    import json
+    import io
+    gold = os.path.join(HERE, "golden")
+    data = open(os.path.join(gold, "identity_hop.bin"), "rb").read()
+    meta = json.load(open(os.path.join(gold, "identity_hop.json")))
+    assert hashlib.sha256(data).hexdigest() == meta["input_sha256"]
+    for name, (c, l, m) in {"default": (128, 32, 1), "best": (1768, 128, 1), "fast": (1, 0, 0), "greedy128": (128, 0, 0)}.items():
+        want = ob.encode(data, opts=ob.make_opts(c, l, m))
+        assert hashlib.sha256(want).hexdigest() == meta["streams"][name]["sha256"], name  # the oracle is the committed one
+        info = agree(da, ctx, data, c, l, m)
+        assert info["q1_rewarm"] == 1, name
+        enc = da.DeflateEncoder(io.BytesIO(), da.CompressionOptions(c, l, m), ctx=ctx)
+        enc.write(data[:50000])
+        enc.write(data[50000:])
+        assert enc.finish().getvalue() == want, (name, "written in two parts")
+    # and the input with the first three windows moved behind a window of other bytes: no re-warm, no such match
+    pre = datagen.text_like(32768, 5)
+    agree(da, ctx, pre + data, *LV["default"])
+
+
+def test_host_call_streamed_in_pieces(da):
+    """mi355_deflate_encode of 16 MiB or more works on the input piece by piece as it arrives and hands the finished bytes
+    back while the later pieces are worked on (run_streamed; MI355_CFG_HOST_STREAMING): the bytes are those of the single
+    pass, i.e. the oracle's -- page-locked buffers (the copy engine carries the pieces) and pageable ones (the runtime's
+    copies), raw / zlib / gzip, the levels with a hash, and the inputs the piecewise form hands to the single pass (noise:
+    the hash re-warm of the first window; zeros: periodic, the speculative entries do not hold)."""
+    import torch
+    ctx = da.Context(0)
+    try:
+        cases = [("text", datagen.text_like(40_000_000, 91), ("default", "fast", "best")),
+                 ("mixed", datagen.mixed(30_000_000, 92) + datagen.text_like(9_000_001, 93), ("default",)),
+                 ("noise", datagen.rng_bytes(33_000_000, 94), ("default",)),
+                 ("zeros", bytes(36_000_000), ("default",))]
+        for name, data, levels in cases:
+            h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+            cap = da.bound(len(data)) + 64
+            h_out = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            for lv in levels:
+                c, l, m = LV[lv]
+                for wrapper in (0, 1, 2):
+                    if wrapper and lv != "default":
+                        continue
+                    want = ob.encode(data, opts=ob.make_opts(c, l, m, wrapper)) if wrapper < 2 else ob.encode_gzip(
+                        data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, m, 0))
+                    for mode in (1, 0, 2):
+                        ctx.config(da.Context.CFG_HOST_STREAMING, mode)
+                        h_out.zero_()
+                        n = ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), cap, da.CompressionOptions(c, l, m),
+                                                wrapper=wrapper)
+                        assert bytes(h_out[:n].numpy()) == want, (name, lv, wrapper, mode, n, len(want))
+                    ctx.config(da.Context.CFG_HOST_STREAMING, 1)
+                    got = ctx.encode(data, da.CompressionOptions(c, l, m), wrapper=wrapper)  # pageable buffers
+                    assert got == want, (name, lv, wrapper, "pageable", len(got), len(want))
+        # an output buffer that is too small for the bound goes the single pass's way and says so only if the bytes do not fit
+        data = cases[0][1]
+        want = ob.encode(data, opts=ob.make_opts(*LV["default"], 0))
+        h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+        h_out = torch.empty(len(want) + 8, dtype=torch.uint8).pin_memory()
+        n = ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), len(want) + 8, da.Compression.Default)
+        assert bytes(h_out[:n].numpy()) == want
+        with pytest.raises(da.DeflateError):
+            ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), len(want) - 1, da.Compression.Default)
+    finally:
+        ctx.close()
+
+
 def test_long_input_walked_in_ranges(da, ctx, small_ranges):
     """One call, several ranges (the phases of the sharded encode one after the other on one GPU, the bit position and
     the unfinished block carried across): the bytes of a single-range call, i.e. of the oracle -- text, zeros (a range

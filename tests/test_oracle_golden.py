@@ -50,3 +50,28 @@ def test_big_digests_are_the_oracles():
         assert gen_big_digests.digest(name, make, level) == gold[name], name
         seen += 1
     assert seen == 3
+
+
+def test_identity_hop_fixture_is_what_it_says():
+    """tests/golden/identity_hop.bin (gen_identity_hop.py): the generator rebuilds the committed bytes, block 0 of the oracle's
+    stream fills at exactly 32768 with 31744 values (the hash re-warm of lz77.rs:628-638 then files 32768 / 32769 under foreign
+    hashes), the oracle's token at 65536 is the match at distance 32768 that only the head table's identity entry can give
+    (chained_hash_table.rs:197-219, matching.rs:102-132), and the streams are the committed digests."""
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import gen_identity_hop
+    import tokdump
+    data = open(os.path.join(HERE, "golden", "identity_hop.bin"), "rb").read()
+    meta = json.load(open(os.path.join(HERE, "golden", "identity_hop.json")))
+    built, z = gen_identity_hop.build()
+    assert built == data and hashlib.sha256(data).hexdigest() == meta["input_sha256"]
+    assert data[32768:32768 + 64] == z == data[65536:65536 + 64]
+    assert gen_identity_hop.hash3(*data[32768:32771]) == 0 and gen_identity_hop.hash3(*data[32769:32772]) == 1
+    for name, (c, l, m) in {"default": (128, 32, 1), "best": (1768, 128, 1), "fast": (1, 0, 0), "greedy128": (128, 0, 0)}.items():
+        s = ob.encode(data, opts=ob.make_opts(c, l, m))
+        tr = ob.trace_blocks()
+        # (one candidate per position misses a few of the planted three-byte copies: the block fills a few bytes early and the
+        # re-filed positions are others -- the match at 65536 is then an ordinary one)
+        assert tr[0]["n_lz"] == 31744 and (tr[0]["in_bytes"] == 32768 or name == "fast"), (name, tr[0])
+        assert hashlib.sha256(s).hexdigest() == meta["streams"][name]["sha256"] and len(s) == meta["streams"][name]["len"], name
+        toks = {t[0]: t for b in tokdump.tokens(s) for t in b["toks"]}
+        assert toks[65536] == (65536, 64, 32768), (name, toks.get(65536))
