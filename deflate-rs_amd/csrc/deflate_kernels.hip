@@ -1760,7 +1760,7 @@ constexpr uint32_t SPEC_W = 128;  // (measured with the repair in place, parse s
 constexpr uint32_t FIX_MAX = 1024;  // listed segments the repair takes on (more: the data is periodic at large, the exact parse is due)
 constexpr uint32_t FIX_HOPS = 24;
 struct SpecFix {
-    uint32_t* list;          // segments whose entry is not the exit of the segment before
+    uint32_t* list;          // segments whose entry is not the exit of the segment before, each with that exit
     uint32_t* badmap;        // the same as a bit per segment
     const uint32_t* n;       // how many
 };
@@ -1782,8 +1782,10 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (MODE == 2) {
         const uint32_t nf = *fix.n;
         if (nf > FIX_MAX || k >= nf) return;
-        k = fix.list[k];
-        given = Xs[k - 1];  // (a listed segment is never the first)
+        // (the exit of the segment before it as k_spec_check saw it -- not Xs[k - 1] as it is now, which a wave that repairs the
+        // segments before this one may be rewriting: what a repair is based on must not depend on which wave runs first)
+        given = fix.list[2 * k + 1];
+        k = fix.list[2 * k];
     }
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
     uint16_t* A = s_adv[wv];
@@ -1927,7 +1929,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
 }
 
 // k_spec_check: after the speculative k_emit, which segments were entered somewhere else than the segment before them was
-// left?  A bit per segment and a list (in no particular order) for the repair; sc->n_fix counts them.
+// left?  A bit per segment and a list (in no particular order; segment and the exit before it) for the repair; sc->n_fix counts them.
 // (lo: the first segment of the range looked at -- a multiple of 64 -- K its end)
 __global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* __restrict__ E0, const uint32_t* __restrict__ Xs,
                                                     uint32_t* __restrict__ badmap, uint32_t* __restrict__ list, uint32_t* __restrict__ n_fix,
@@ -1944,7 +1946,10 @@ __global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* 
     if (lane == 0) at = atomicAdd(n_fix, (uint32_t)__popcll(m));
     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (off && at + rank < FIX_MAX) list[at + rank] = i;
+    if (off && at + rank < FIX_MAX) {
+        list[2 * (at + rank)] = i;
+        list[2 * (at + rank) + 1] = Xs[i - 1];  // what the repair parses the segment from
+    }
 }
 
 // k_scan_a / k_scan_b: exclusive scan of the per-segment token counts.  A workgroup takes 1024

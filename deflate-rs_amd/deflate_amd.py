@@ -170,6 +170,7 @@ def load():
     L.mi355_checksum_combine.restype = C.c_uint32
     L.mi355_deflate_stream_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mi355_deflate_stream_free.argtypes = [C.c_void_p]
+    L.mi355_device_count.restype = C.c_int
     L.mi355_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.mi355_multi_destroy.argtypes = [C.c_void_p]
     L.mi355_multi_destroy.restype = None
@@ -207,7 +208,7 @@ EXPORTED = [
     "mi355_plan_blocks",
     "mi355_shard_pack", "mi355_shard_end", "mi355_checksum_combine",
     "mi355_deflate_ctx_config", "mi355_deflate_stream_held_bytes",
-    "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_devices", "mi355_multi_ctx", "mi355_multi_last_error",
+    "mi355_device_count", "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_devices", "mi355_multi_ctx", "mi355_multi_last_error",
     "mi355_multi_layout", "mi355_deflate_encode_multi", "mi355_deflate_encode_multi_device", "mi355_multi_last_trace",
 ]
 
@@ -557,10 +558,15 @@ class MultiGpu:
     TRACE = ["tables", "wait1", "tokens", "wait2", "block costs", "wait3", "plan+pack+copy", "wait4", "seams+framing",
              "host work of the exchanges", "call"]
 
-    def __init__(self, devices):
-        arr = (C.c_int * len(devices))(*devices)
+    def __init__(self, devices=None):
+        """devices=None: every device of the node"""
         h = C.c_void_p()
-        rc = load().mi355_multi_create(arr, len(devices), C.byref(h))
+        if devices is None:
+            rc = load().mi355_multi_create(None, 0, C.byref(h))
+            devices = list(range(load().mi355_device_count()))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = load().mi355_multi_create(arr, len(devices), C.byref(h))
         if rc != OK:
             raise DeflateError(rc, "cannot create contexts on HIP devices %r" % (list(devices),))
         self._h = h
@@ -579,6 +585,12 @@ class MultiGpu:
 
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_multi_last_error(self._h).decode())
+
+    def config(self, key, value):
+        """mi355_deflate_ctx_config of rank 0's context (CFG_RANGE_BYTES: twice that is the most one rank takes)"""
+        rc = load().mi355_deflate_ctx_config(C.c_void_p(load().mi355_multi_ctx(self._h, 0)), key, value)
+        if rc != OK:
+            self._err(rc)
 
     def layout(self, in_len, rank):
         """-> dict(n_ranks, g_lo, g_hi, lo, hi): the bytes rank `rank` holds and owns"""

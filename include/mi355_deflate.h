@@ -266,22 +266,34 @@ uint32_t mi355_checksum_combine(int kind, uint32_t sum_a, uint32_t sum_b, uint64
  * goes through host memory, and the packed byte ranges land at their offsets in `out`, the word two neighbours share
  * OR-ed in.  The bytes are those of ONE encoder over the whole input, i.e. the reference's.
  *   _create    devices[i] = HIP device of rank i (a device may be named more than once: ranks then share it --
- *              how a one-GPU box tests the N-rank path); n_devices <= 64
+ *              how a one-GPU box tests the N-rank path); n_devices <= 64; devices == NULL with n_devices == 0: every
+ *              device of the node (mi355_device_count of them, in HIP's order)
+ * A handle serves ONE call at a time: the encode calls hold its lock from entry to return, calls from several threads
+ * are safe and serialised, and the calling thread's current HIP device is what it was when the call returns.
+ * Size: a rank is one pass of the pipeline (32-bit positions, about 20 B of device memory per byte of its range), so an
+ * input of more than 2 x MI355_CFG_RANGE_BYTES of rank 0's context per device (default: 1 GiB per device) is cut into
+ * MORE ranks than devices -- rank r lives on device r % n_devices, the ranks of a device run one after the other in
+ * every phase, each with a context of its own -- up to 64 ranks (64 GiB with the default).  Beyond that the host-buffer
+ * call goes through the single-device call of rank 0, which walks any length in ranges; the device-resident call,
+ * whose shards the caller lays out, returns MI355_E_UNSUPPORTED (raise MI355_CFG_RANGE_BYTES: up to 3 GiB, 384 GiB).
  *   _encode_multi         host buffers in and out (ctx-less: the handle owns its contexts); wrapper 0 / 1 / 2 as in
  *              mi355_deflate_opts, `gz_hdr` = GzBuilder::into_header() for wrapper 2 (NULL: the blank header);
  *              out_cap >= mi355_deflate_bound_ex(in_len, wrapper, gz_len, 0); an input of less than 1 MiB per
  *              device uses fewer devices (down to the plain single-device call)
  *   _layout    which bytes rank `rank` holds for an input of in_len bytes: [g_lo, g_hi) of the input, of which
- *              [lo, hi) is its own range; *n_ranks = the ranks that take part (rank >= *n_ranks: nothing)
- *   _encode_multi_device  the same with the input already resident: d_ext[r] = device pointer, on rank r's device,
- *              to the bytes [g_lo, g_hi) of _layout (+ 64 readable bytes behind them); d_out = device buffer on
+ *              [lo, hi) is its own range; *n_ranks = the ranks that take part (rank >= *n_ranks: nothing) -- fewer than
+ *              the devices for a short input, more for a long one (rank r on device r % n_devices)
+ *   _encode_multi_device  the same with the input already resident: d_ext[r] = device pointer, on rank r's device
+ *              (device r % n_devices), to the bytes [g_lo, g_hi) of _layout (+ 64 readable bytes behind them); d_out = device buffer on
  *              rank 0's device (4-byte aligned).  The packed ranges reach it by peer copies (hipMemcpyPeer: xGMI
  *              between the GPUs of a node) -- the only GPU-to-GPU traffic of the call
- *   _ctx       rank r's context (mi355_deflate_last_info of it: that rank's match-kernel time ...)
+ *   _ctx       rank r's context (mi355_deflate_last_info of it: that rank's match-kernel time ...; NULL for a rank no
+ *              call has needed yet)
  *   _last_trace  rank 0's wall clock of the last call in ms: [0] bytes + tables, [1] wait, [2] entry + tokens,
  *              [3] wait, [4] block costs, [5] wait, [6] plan + pack + copy-out, [7] wait, [8] seams + framing,
  *              [9] host work of the exchanges (entries, token plan, tails, block plan, seams), [10] the whole call */
 typedef struct mi355_multi mi355_multi;
+int mi355_device_count(void); /* HIP devices this process sees (0: none, or no HIP runtime); for callers that do not link HIP */
 int mi355_multi_create(const int* devices, int n_devices, mi355_multi** out);
 void mi355_multi_destroy(mi355_multi* m);
 int mi355_multi_devices(const mi355_multi* m);

@@ -80,3 +80,26 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
            "-lmi355deflate", "-Wl,-rpath," + os.path.join(root, "deflate-rs_amd"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+# what a host shim in another language does (rust/deflate-mi355: build.rs emits -lmi355deflate and nothing else): a program that
+# names EVERY entry of the header -- and the symbols the Rust shim declares in its extern blocks -- links against the library
+# alone.  (Round 4's shim named hipGetDeviceCount, which lives in libamdhip64: "DSO missing from command line".)
+def test_every_entry_links_against_the_library_alone(tmp_path):
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "mi355_deflate.h")).read()
+    product_hdr = re.sub(r"#ifdef MI355_DEBUG_HOOKS.*?#endif", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", product_hdr)))
+    rs = open(os.path.join(ROOT, "rust", "deflate-mi355", "src", "lib.rs")).read()
+    rust_externs = sorted(set(re.findall(r"^\s*fn ([A-Za-z0-9_]+)\s*\(", "\n".join(re.findall(r'extern "C" \{(.*?)^\}', rs, flags=re.S | re.M)),
+                                         flags=re.M)))
+    assert rust_externs and all(n.startswith("mi355_") for n in rust_externs), rust_externs
+    assert set(rust_externs) <= set(declared), sorted(set(rust_externs) - set(declared))
+    src = tmp_path / "all.c"
+    src.write_text('#include "mi355_deflate.h"\n#include <stdio.h>\nint main(void) {\n  void* p[] = {\n' +
+                   "".join("    (void*)%s,\n" % n for n in declared) + "  };\n  printf(\"%d\\n\", (int)(sizeof p / sizeof p[0]));\n  return p[0] == 0;\n}\n")
+    exe = str(tmp_path / "all")
+    cmd = ["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-L", os.path.join(ROOT, "deflate-rs_amd"),
+           "-lmi355deflate", "-Wl,-rpath," + os.path.join(ROOT, "deflate-rs_amd"), "-Wl,--no-copy-dt-needed-entries", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -561,6 +561,52 @@ def test_multi_gpu_encode_in_one_call(da, world):
         m.close()
 
 
+def test_multi_gpu_more_ranks_than_devices(da):
+    """An input beyond what one rank takes per device (2 x MI355_CFG_RANGE_BYTES of rank 0's context) is cut into MORE ranks
+    than devices -- rank r on device r % n, the ranks of a device one after the other in every phase: no size ceiling short of
+    the devices' memory (round-4 review: 8 GiB over two devices was MI355_E_UNSUPPORTED).  With 16 MiB ranges: two devices,
+    four ranks each, against the oracle -- host buffers and resident shards, raw / zlib / gzip, and the handle serialises
+    callers (two threads on one handle)."""
+    import threading
+    import torch
+    m = da.MultiGpu([0, 0])
+    try:
+        m.config(da.Context.CFG_RANGE_BYTES, 16 << 20)
+        data = datagen.text_like(150_000_000, 0xE1)[:-7] + datagen.rng_bytes(3_000_000, 0xE2) + bytes(9_000_000) + datagen.mixed(40_000_000, 0xE3)
+        lay = [m.layout(len(data), r) for r in range(8)]
+        assert lay[0]["n_ranks"] == 8 and lay[0]["lo"] == 0 and lay[7]["hi"] == len(data)
+        assert all(lay[r]["hi"] - lay[r]["lo"] <= (32 << 20) + 8 * 32768 for r in range(8))
+        c, l, mt = LV["default"]
+        for wrapper in (0, 1, 2):
+            want = ob.encode(data, opts=ob.make_opts(c, l, mt, wrapper)) if wrapper < 2 else ob.encode_gzip(
+                data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, mt, 0))
+            got = m.encode(data, da.Compression.Default, wrapper=wrapper)
+            assert got == want, (wrapper, len(got), len(want))
+        want = ob.encode(data, opts=ob.make_opts(c, l, mt, 0))
+        bufs = [torch.frombuffer(bytearray(data[L["g_lo"]:L["g_hi"]]) + bytearray(64), dtype=torch.uint8).cuda() for L in lay]
+        cap = da.bound(len(data)) + 64
+        d_out = torch.full((cap,), 0x55, dtype=torch.uint8, device="cuda")
+        n = m.encode_device([b.data_ptr() for b in bufs], len(data), d_out.data_ptr(), cap, da.Compression.Default)
+        assert bytes(d_out[:n].cpu().numpy()) == want
+        # a level with few tokens per range (ranges shorter than a block: tails made of several ranks' heads)
+        z = bytes(70_000_000)
+        assert m.encode(z, da.CompressionOptions(*LV["rle"])) == ob.encode(z, opts=ob.make_opts(*LV["rle"], 0))
+        # two callers on one handle: the calls follow each other
+        small = data[:40_000_000]
+        want_small = ob.encode(small, opts=ob.make_opts(c, l, mt, 1))
+        res = [None, None]
+
+        def call(i):
+            res[i] = m.encode(small, da.Compression.Default, wrapper=1)
+        th = [threading.Thread(target=call, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert res[0] == want_small and res[1] == want_small
+        assert torch.cuda.current_device() == 0
+    finally:
+        m.close()
+
+
 def test_multi_gpu_encode_device_resident(da):
     """The same call with every rank's bytes already on its device and the stream assembled in rank 0's device memory:
     the packed ranges arrive by peer copies, the seam words by one small kernel."""
