@@ -422,6 +422,9 @@ def main():
                 "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % world},
             "out_bytes": total_out, "ratio": round(total_out / (world * size), 5),
             "gpu_ms_per_step_events": round(sum(gpu_ms) / len(gpu_ms), 3),
+            # every timed step by its own HIP events (first kernel to last): one noisy step shows here, not only in the mean
+            "step_ms_events": {"min": round(min(gpu_ms), 3), "median": round(sorted(gpu_ms)[len(gpu_ms) // 2], 3),
+                               "max": round(max(gpu_ms), 3), "n": len(gpu_ms)},
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -439,13 +442,19 @@ def main():
             ctx.reserve(size, host_api=True)
             ctx.encode_host_ptr(h_in.data_ptr(), size, h_out.data_ptr(), cap + 64, options)
             reps = max(2, args.steps)
+            calls = []
             t1 = time.perf_counter()
             for _ in range(reps):
+                tc = time.perf_counter()
                 hn = ctx.encode_host_ptr(h_in.data_ptr(), size, h_out.data_ptr(), cap + 64, options)
+                calls.append((time.perf_counter() - tc) * 1e3)  # (the call returns when the last byte has landed)
             dt = time.perf_counter() - t1
             res["value_host_api"] = {"value": round(size * reps / dt / 1e6, 2), "unit": "MB/s",
                                      "ms_per_call": round(dt * 1e3 / reps, 3),
-                                     "what": "mi355_deflate_encode on pinned host buffers, H2D + encode + D2H",
+                                     "call_ms": {"min": round(min(calls), 3), "median": round(sorted(calls)[len(calls) // 2], 3),
+                                                 "max": round(max(calls), 3), "n": len(calls)},
+                                     "what": "mi355_deflate_encode on pinned host buffers, first H2D byte to last D2H byte (pieces: H2D, "
+                                             "kernels and the copy engine's D2H overlap)",
                                      "same_bytes": bool(hn == out_len[0] and torch.equal(
                                          h_out[:hn], d_out[:hn].cpu()))}
         if world == 1 and not args.no_cpu_baseline:

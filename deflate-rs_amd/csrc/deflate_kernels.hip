@@ -984,13 +984,13 @@ struct MsGroup {
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, a0, a1, a2, a3, a4, a5, a6, a7, probe;
 };
 __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, uint32_t* asel_out, uint32_t* back_out) {
+    // e_i: the lanes whose FIRST hit is probe i (one-hot per lane)
     const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe);
     const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & ~e0m;
     const uint64_t e2m = __builtin_amdgcn_ballot_w64(st.t2 == st.probe) & ~(e0m | e1m);
     uint64_t any = e0m | e1m | e2m;
     const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & ~any;
     any |= e3m;
-    uint32_t asel, back;
     const uint64_t e4m = __builtin_amdgcn_ballot_w64(st.t4 == st.probe) & ~any;
     any |= e4m;
     const uint64_t e5m = __builtin_amdgcn_ballot_w64(st.t5 == st.probe) & ~any;
@@ -999,6 +999,8 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     any |= e6m;
     const uint64_t e7m = __builtin_amdgcn_ballot_w64(st.t7 == st.probe) & ~any;
     any |= e7m;
+#ifndef MI355_DECODE_TREE  // fourteen selects in two chains
+    uint32_t asel, back;
     asel = __builtin_amdgcn_inverse_ballot_w64(e7m) ? st.a7 : st.a0;
     back = __builtin_amdgcn_inverse_ballot_w64(e7m) ? 2u : 16u;
     asel = __builtin_amdgcn_inverse_ballot_w64(e6m) ? st.a6 : asel;
@@ -1013,6 +1015,22 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 12u : back;
     asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
     back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 14u : back;
+#else
+    // (round 5, measured and not kept: the stopping step as three lane masks and a tree of selects -- ten selects instead of
+    // fourteen, nine scalar ORs more -- 3.58 -> 3.63 ms, Best 5.55 -> 5.64 on one box.  On gfx950 a select, a compare, anything in a
+    // three-operand, SDWA or DPP encoding holds the SIMD 1.75 times as long as a plain add / and / or / xor / right shift
+    // (tools/probes/valu_ops.hip), but the kernel is not a sum of such prices: the scalar work of a wave is latency of that wave.)
+    const uint64_t b0 = e1m | e3m | e5m | e7m, b1 = e2m | e3m | e6m | e7m, b2 = e4m | e5m | e6m | e7m;
+    const bool l0 = __builtin_amdgcn_inverse_ballot_w64(b0), l1 = __builtin_amdgcn_inverse_ballot_w64(b1),
+               l2 = __builtin_amdgcn_inverse_ballot_w64(b2);
+    const uint32_t s01 = l0 ? st.a1 : st.a0, s23 = l0 ? st.a3 : st.a2, s45 = l0 ? st.a5 : st.a4, s67 = l0 ? st.a7 : st.a6;
+    const uint32_t s03 = l1 ? s23 : s01, s47 = l1 ? s67 : s45;
+    const uint32_t asel = l2 ? s47 : s03;
+    // back = 16 - 2 k (a lane without a hit: k = 0, the end of its group)
+    uint32_t back = l0 ? 14u : 16u;
+    back = l1 ? back - 4u : back;
+    back = l2 ? back - 8u : back;
+#endif
     *any_out = any;
     *asel_out = asel;
     *back_out = back;

@@ -207,6 +207,11 @@ def webtext_segment(index, seed=0x57454254):
     return (np.concatenate(out) if len(out) > 1 else out[0])[:WEB_SEGMENT]
 
 
+def webtext_segment_bytes(index):
+    """(a top-level function for process pools: the 8 GiB of config 5 are generated on all cores)"""
+    return webtext_segment(index).tobytes()
+
+
 def webtext(n, seed=0x57454254, start=0):
     """bytes [start, start + n) of the web-text workload"""
     first, last = start // WEB_SEGMENT, (start + n + WEB_SEGMENT - 1) // WEB_SEGMENT

@@ -226,7 +226,24 @@ class Stream:
     def output(self) -> bytes:
         p = C.POINTER(C.c_uint8)()
         n = lib().deflref_stream_output(self._s, C.byref(p))
-        return bytes(C.string_at(p, n)) if n else b""
+        if not n:
+            return b""
+        if n < (1 << 31):
+            return bytes(C.string_at(p, n))
+        # (ctypes.string_at takes a C int: the 8 GiB stream of config 5 is 2.9 GB)
+        return bytes((C.c_uint8 * n).from_address(C.addressof(p.contents)))
+
+    def output_sha256(self):
+        """(length, SHA-256) of the stream so far without a copy of it"""
+        import hashlib
+        p = C.POINTER(C.c_uint8)()
+        n = lib().deflref_stream_output(self._s, C.byref(p))
+        h = hashlib.sha256()
+        step = 1 << 28
+        for i in range(0, n, step):
+            k = min(step, n - i)
+            h.update((C.c_uint8 * k).from_address(C.addressof(p.contents) + i))
+        return n, h.hexdigest()
 
     def checksum(self):
         return lib().deflref_stream_checksum(self._s)

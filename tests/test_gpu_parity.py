@@ -353,6 +353,61 @@ def test_config5_webtext_sharded_over_8_virtual_ranks(da, ctx):
     assert one == got
 
 
+# BASELINE config 5 at its stated size: 8 GiB of the web-text input, against the oracle's digests of the whole stream
+# (tests/golden/config5_digest.json, gen_config5_digest.py: six minutes of oracle).  The input is generated on the box's cores a
+# MiB segment at a time straight into device memory; (a) one GPU walks it in 512 MiB ranges (mi355_deflate_encode_device), raw and
+# zlib; (b) mi355_deflate_encode_multi_device cuts it over eight ranks of 1 GiB -- here all on this one device.
+def test_config5_at_8_gib(da):
+    import hashlib
+    import json
+    import multiprocessing as mp
+    import torch
+    gold = json.load(open(os.path.join(HERE, "golden", "config5_digest.json")))["digests"]
+    N = gold["raw"]["in_len"]
+    assert N == 8 << 30
+    d_in = torch.empty(N + 64, dtype=torch.uint8, device="cuda")
+    d_in[N:] = 0
+    hin = hashlib.sha256()
+    per = 64
+    with mp.get_context("spawn").Pool(min(48, max(2, (os.cpu_count() or 4) - 2))) as pool:
+        pending = []
+        nxt, done, n_seg = 0, 0, N // datagen.WEB_SEGMENT
+        while done < N:
+            while len(pending) < 4 and nxt < n_seg:
+                pending.append(pool.map_async(datagen.webtext_segment_bytes, range(nxt, min(nxt + per, n_seg)), chunksize=2))
+                nxt = min(nxt + per, n_seg)
+            b = b"".join(pending.pop(0).get())
+            hin.update(b)
+            d_in[done:done + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+            done += len(b)
+    assert hin.hexdigest() == gold["raw"]["in_sha256"]
+
+    def digest_of(d_out, n):
+        h = hashlib.sha256()
+        for i in range(0, n, 256 << 20):
+            h.update(bytes(d_out[i:min(n, i + (256 << 20))].cpu().numpy()))
+        return [n, h.hexdigest()]
+    cap = da.bound(N) + 64
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    ctx = da.Context(0)
+    try:
+        for name, wrapper in (("raw", 0), ("zlib", 1)):
+            n = ctx.encode_device(d_in.data_ptr(), N, d_out.data_ptr(), cap, da.Compression.Default, wrapper=wrapper)
+            assert ctx.info()["passes"] >= 16, "8 GiB are sixteen ranges of 512 MiB"
+            assert digest_of(d_out, n) == [gold[name]["out_len"], gold[name]["out_sha256"]], name
+    finally:
+        ctx.close()
+    m = da.MultiGpu([0] * 8)
+    try:
+        lay = [m.layout(N, r) for r in range(8)]
+        assert lay[0]["n_ranks"] == 8 and all(L["hi"] - L["lo"] == 1 << 30 for L in lay)
+        d_out.fill_(0x33)
+        n = m.encode_device([d_in.data_ptr() + L["g_lo"] for L in lay], N, d_out.data_ptr(), cap, da.Compression.Default)
+        assert digest_of(d_out, n) == [gold["raw"]["out_len"], gold["raw"]["out_sha256"]], "eight ranks"
+    finally:
+        m.close()
+
+
 # MI355_FLUSH_SYNC == fresh reference encoder: write_all(chunk); flush() (writer.rs:134-137,
 # compress.rs:256-261) -- the chunk form the multi-GPU stitch concatenates
 def test_sync_flush_chunks_and_stitch(da, ctx):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# final evidence of a round (GPU box, from the repo root): tools/final_evidence.sh TAG   (default r04)
-TAG=${1:-r04}
+# final evidence of a round (GPU box, from the repo root): tools/final_evidence.sh TAG   (default r05)
+TAG=${1:-r05}
 set -x
 timeout 2000 python -m pytest tests/ -m gpu -x -q > gpurun_out/${TAG}_gpu_suite.txt 2>&1; tail -3 gpurun_out/${TAG}_gpu_suite.txt
 timeout 900 python tools/make_profiles.py $TAG > gpurun_out/${TAG}_make_profiles.log 2>&1; tail -25 gpurun_out/${TAG}_make_profiles.log
@@ -12,3 +12,8 @@ timeout 300 python tools/kernel_stats.py sort > gpurun_out/${TAG}_k_sort_clock_s
 # the multi-GPU call on this one device (dry run: the ranks' kernels queue on one GPU; what it shows is the host side of the exchanges)
 for n in 2 4 8; do timeout 300 python bench.py --gpus $n --single-process --virtual --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_multi_virtual_N$n.json; python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_multi_virtual_N$n.json')); print($n, d['value'], d['ms_per_step'], d.get('multi_trace_ms'))"; done
+# BASELINE config 5 at 8 GiB: one GPU's range walk and eight ranks on this one device, against the oracle's digest
+timeout 900 python tools/config5_8gib.py --virtual 8 2>/dev/null | tail -1 > gpurun_out/${TAG}_config5_8gib.json; cat gpurun_out/${TAG}_config5_8gib.json
+# a timed region of more than a second (the default line's 20 steps are 0.1 s)
+timeout 600 python bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_300_steps.json; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_300_steps.json')); print('300 steps:', d['value'], d['ms_per_step'], d['step_ms_events'], d['value_host_api'])"
