@@ -124,11 +124,17 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          one) and the finished bytes leave on the copy engine while the later pieces are worked on;
  *                          0 = one copy-out after the last kernel; 2 = pieces with their stages behind each other
  *                          (a measuring aid).  Same bytes every way; data the piecewise form does not take (a hash re-warm
- *                          in the first window, long periodic data) is encoded the other way without the caller noticing. */
+ *                          in the first window, long periodic data) is encoded the other way without the caller noticing.
+ *   MI355_CFG_MULTI_STITCH  (of rank 0's context of a mi355_multi handle: mi355_multi_ctx(m, 0)) how the packed ranges of
+ *                          mi355_deflate_encode_multi_device reach rank 0's device: 0 (default) = peer copies
+ *                          (hipMemcpyPeerAsync: xGMI between the GPUs of a node), 1 = RCCL -- one ncclSend per rank, the
+ *                          matching ncclRecv posted by rank 0's thread straight into the caller's buffer; librccl.so is
+ *                          looked up when the first such call is made (MI355_E_UNSUPPORTED if it is not there). */
 #define MI355_CFG_RANGE_BYTES 1
 #define MI355_CFG_LONG_FROM 2
 #define MI355_CFG_SORT_RANKS 3
 #define MI355_CFG_HOST_STREAMING 4
+#define MI355_CFG_MULTI_STITCH 5
 int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers

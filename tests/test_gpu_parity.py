@@ -662,13 +662,17 @@ def test_multi_gpu_more_ranks_than_devices(da):
         m.close()
 
 
-def test_multi_gpu_encode_device_resident(da):
+@pytest.mark.parametrize("stitch", [0, 1])
+def test_multi_gpu_encode_device_resident(da, stitch):
     """The same call with every rank's bytes already on its device and the stream assembled in rank 0's device memory:
-    the packed ranges arrive by peer copies, the seam words by one small kernel."""
+    the packed ranges arrive by peer copies (stitch 0) or by ncclSend / ncclRecv (MI355_CFG_MULTI_STITCH = 1: RCCL found at
+    run time; with the ranks on one device every pair is a send to and a receive from the communicator's own rank), the seam
+    words by one small kernel."""
     import torch
     for world in (2, 4):
         m = da.MultiGpu([0] * world)
         try:
+            m.config(da.Context.CFG_MULTI_STITCH, stitch)
             for data, lv, wrapper in ((datagen.text_like(9_000_000, 0xD1), "default", 0), (datagen.mixed(7_000_000, 0xD2), "best", 1),
                                       (bytes(10_000_000), "default", 2), (datagen.rng_bytes(5_000_000, 0xD3), "default", 0)):
                 c, l, mt = LV[lv]

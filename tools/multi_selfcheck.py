@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=0, help="devices to use (0: all)")
     ap.add_argument("--mb-per-gpu", type=int, default=32)
+    ap.add_argument("--no-rccl", action="store_true", help="skip the resident case with the RCCL stitch (MI355_CFG_MULTI_STITCH = 1)")
     args = ap.parse_args()
     import torch  # noqa: F401  (before the library: tests/test_gpu_parity.py)
     import datagen
@@ -64,14 +65,20 @@ def main():
         d_out = torch.full((cap,), 0xAA, dtype=torch.uint8, device="cuda:0")
         for d in range(n):
             torch.cuda.synchronize(d)
-        t0 = time.time()
-        k = m.encode_device([b.data_ptr() for b in bufs], len(data), d_out.data_ptr(), cap, da.Compression.Default)
-        dt = time.time() - t0
         want = ob.encode(data, opts=ob.make_opts(c, l, mt, 0))
-        same = bytes(d_out[:k].cpu().numpy()) == want
-        res["cases"].append({"input": name, "bytes": len(data), "wrapper": 0, "form": "resident", "same": same, "ranks": W,
-                             "ms": round(dt * 1e3, 2), "MB/s": round(len(data) / dt / 1e6, 1), "trace": m.trace()})
-        res["ok"] = res["ok"] and same
+        for stitch in ((0,) if args.no_rccl else (0, 1)):  # peer copies, then ncclSend / ncclRecv
+            m.config(da.Context.CFG_MULTI_STITCH, stitch)
+            d_out.fill_(0xAA)
+            for d in range(n):
+                torch.cuda.synchronize(d)
+            t0 = time.time()
+            k = m.encode_device([b.data_ptr() for b in bufs], len(data), d_out.data_ptr(), cap, da.Compression.Default)
+            dt = time.time() - t0
+            same = bytes(d_out[:k].cpu().numpy()) == want
+            res["cases"].append({"input": name, "bytes": len(data), "wrapper": 0, "form": "resident, " + ("RCCL stitch" if stitch else "peer copies"),
+                                 "same": same, "ranks": W, "ms": round(dt * 1e3, 2), "MB/s": round(len(data) / dt / 1e6, 1), "trace": m.trace()})
+            res["ok"] = res["ok"] and same
+        m.config(da.Context.CFG_MULTI_STITCH, 0)
     res["seconds"] = round(time.time() - t_all, 1)
     m.close()
     print(json.dumps(res))
