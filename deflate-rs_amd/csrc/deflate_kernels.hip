@@ -619,6 +619,12 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
     KS_T(stat0 + 2)
 }
 
+#ifndef MI355_SORT_HOT
+#define MI355_SORT_HOT 4     // lanes on the first lane's digit from which they are ranked by lane order instead of queueing on the counter
+#endif
+#ifndef MI355_SORT_ROUNDS
+#define MI355_SORT_ROUNDS 1  // (measured on the 100 MB text: k_sort 0.440 ms without, 0.427 with one digit from 4 / 8 lanes on, 0.43 from 16;
+#endif                       //  two / three digits that way 0.47 / 0.50 -- every round is a dependent read and write of the counter)
 #ifndef MI355_SORT_SB
 #define MI355_SORT_SB 4  // batches whose digits are fetched together in the count phase of sort_pass_rtn
 #endif
@@ -648,20 +654,32 @@ __device__ __forceinline__ void sort_pass_rtn(uint32_t J, uint32_t* cnt /*16 * 2
         const uint32_t i = cb + 64 * b + lane;
         const bool valid = i < Jc;
         const uint32_t d = valid ? dig(i) : 0u;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
         const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
         uint32_t r = 0;
-        if (__builtin_amdgcn_ballot_w64(valid && d != d0) == 0) {  // one digit (lane 0 is valid whenever any lane is)
-            const uint32_t nv = (uint32_t)__popcll(vm);
-            uint32_t at = 0;
-            if (nv) at = mine[d0];
+        // The lanes that share the FIRST lane's digit take their ranks from the lane order (one read and one write of the
+        // counter for all of them); only the others queue on their counters.  In the second pass a batch's keys share their
+        // low digit, text has few trigrams per low digit, and half a batch meets on one counter: served one lane after the other.
+        // (MI355_SORT_ROUNDS digits that way, each the digit of the first lane not yet ranked)
+        uint64_t left = vm;
+        bool mine_done = !valid;
+#pragma unroll
+        for (int round = 0; round < MI355_SORT_ROUNDS; round++) {
+            if (left == 0) break;
+            const uint32_t first = (uint32_t)__builtin_ctzll(left);
+            const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)first);
+            const uint64_t mk = __builtin_amdgcn_ballot_w64(!mine_done && d == dk);
+            const uint32_t nk = (uint32_t)__popcll(mk);
+            if (nk < MI355_SORT_HOT) break;
+            const uint32_t at = mine[dk];
             wave_lds_fence();
-            r = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-            if (lane == 0 && nv) mine[d0] = at + nv;
+            const bool hot = !mine_done && d == dk;
+            if (hot) r = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (lane == first) mine[dk] = at + nk;
             wave_lds_fence();
-        } else if (valid) {
-            r = atomicAdd(&mine[d], 1u);
+            mine_done = mine_done || hot;
+            left &= ~mk;
         }
+        if (!mine_done) r = atomicAdd(&mine[d], 1u);
         if ((b & 3) == 0)
             dc[b >> 2] = d;
         else
