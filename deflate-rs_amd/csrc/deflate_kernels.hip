@@ -761,9 +761,18 @@ __global__ __launch_bounds__(1024) void k_lds_order_test(uint32_t rounds, uint32
 #ifndef MI355_SORT_P1
 #define MI355_SORT_P1 8
 #endif
+// What the first kernel of a small call does on the side (run_encode): the call's scalars cleared and the one segment end set,
+// instead of two fills of the runtime in front of it.
+struct SortInit {
+    uint32_t* sc;
+    uint32_t sc_words;
+    uint32_t* seg_end;
+    uint32_t seg_val;
+};
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, uint32_t n, HashOverride ov,
-                                               uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl) {
+                                               uint16_t* __restrict__ Sg, uint16_t* __restrict__ Bg, uint32_t e0, uint32_t dbl,
+                                               SortInit init) {
     __shared__ __attribute__((aligned(16))) uint16_t sH[WINDOW_SIZE];  // hashes; the sorted array at the end
     __shared__ __attribute__((aligned(16))) uint32_t sBuf[WINDOW_SIZE / 2];  // histogram (u16 pairs), then pass-1 output (u16) / cursors
     __shared__ uint32_t sCnt[16 * 256];
@@ -771,6 +780,10 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     __shared__ uint32_t s_runs;  // pieces of 512 positions that lie in a run of one byte
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_runs = 0;
+    if (init.sc && blockIdx.x == 0) {
+        for (uint32_t i = tid; i < init.sc_words; i += 1024) init.sc[i] = 0;
+        if (tid == 0 && init.seg_end) *init.seg_end = init.seg_val;
+    }
     const uint32_t e = e0 + blockIdx.x;
     const uint64_t E = (uint64_t)e * WINDOW_SIZE;
     const uint32_t J = epoch_active(n, E);
@@ -2255,8 +2268,12 @@ static_assert(MAX_BUFFER_LENGTH % PSPLIT == 0, "parts of equal size");
 
 __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                                     uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq,
-                                                    BlockTab tab, uint32_t piece) {
+                                                    BlockTab tab, uint32_t piece, uint32_t* __restrict__ clear, uint32_t clear_words) {
     __shared__ uint32_t h[320];
+    // (a small call's output buffer is cleared here -- k_pack ORs its bits in -- instead of by a fill of its own in front of
+    // k_plan: two launches of the runtime on the way of a 0.3 ms call)
+    if (clear)
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < clear_words; i += gridDim.x * 256) clear[i] = 0;
     const uint32_t b = sc->nbcum[piece] + blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
     if (b >= sc->nb || spec_failed(sc)) return;
     for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
