@@ -1015,56 +1015,24 @@ struct MsGroup {
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, a0, a1, a2, a3, a4, a5, a6, a7, probe;
 };
 __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, uint32_t* asel_out, uint32_t* back_out) {
-    // e_i: the lanes whose FIRST hit is probe i (one-hot per lane)
-    const uint64_t e0m = __builtin_amdgcn_ballot_w64(st.t0 == st.probe);
-    const uint64_t e1m = __builtin_amdgcn_ballot_w64(st.t1 == st.probe) & ~e0m;
-    const uint64_t e2m = __builtin_amdgcn_ballot_w64(st.t2 == st.probe) & ~(e0m | e1m);
-    uint64_t any = e0m | e1m | e2m;
-    const uint64_t e3m = __builtin_amdgcn_ballot_w64(st.t3 == st.probe) & ~any;
-    any |= e3m;
-    const uint64_t e4m = __builtin_amdgcn_ballot_w64(st.t4 == st.probe) & ~any;
-    any |= e4m;
-    const uint64_t e5m = __builtin_amdgcn_ballot_w64(st.t5 == st.probe) & ~any;
-    any |= e5m;
-    const uint64_t e6m = __builtin_amdgcn_ballot_w64(st.t6 == st.probe) & ~any;
-    any |= e6m;
-    const uint64_t e7m = __builtin_amdgcn_ballot_w64(st.t7 == st.probe) & ~any;
-    any |= e7m;
-#ifndef MI355_DECODE_TREE  // fourteen selects in two chains
-    uint32_t asel, back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e7m) ? st.a7 : st.a0;
-    back = __builtin_amdgcn_inverse_ballot_w64(e7m) ? 2u : 16u;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e6m) ? st.a6 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e6m) ? 4u : back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e5m) ? st.a5 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e5m) ? 6u : back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e4m) ? st.a4 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e4m) ? 8u : back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e3m) ? st.a3 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e3m) ? 10u : back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e2m) ? st.a2 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e2m) ? 12u : back;
-    asel = __builtin_amdgcn_inverse_ballot_w64(e1m) ? st.a1 : asel;
-    back = __builtin_amdgcn_inverse_ballot_w64(e1m) ? 14u : back;
-#else
-    // (round 5, measured and not kept: the stopping step as three lane masks and a tree of selects -- ten selects instead of
-    // fourteen, nine scalar ORs more -- 3.58 -> 3.63 ms, Best 5.55 -> 5.64 on one box.  On gfx950 a select, a compare, anything in a
-    // three-operand, SDWA or DPP encoding holds the SIMD 1.75 times as long as a plain add / and / or / xor / right shift
-    // (tools/probes/valu_ops.hip), but the kernel is not a sum of such prices: the scalar work of a wave is latency of that wave.)
-    const uint64_t b0 = e1m | e3m | e5m | e7m, b1 = e2m | e3m | e6m | e7m, b2 = e4m | e5m | e6m | e7m;
-    const bool l0 = __builtin_amdgcn_inverse_ballot_w64(b0), l1 = __builtin_amdgcn_inverse_ballot_w64(b1),
-               l2 = __builtin_amdgcn_inverse_ballot_w64(b2);
-    const uint32_t s01 = l0 ? st.a1 : st.a0, s23 = l0 ? st.a3 : st.a2, s45 = l0 ? st.a5 : st.a4, s67 = l0 ? st.a7 : st.a6;
-    const uint32_t s03 = l1 ? s23 : s01, s47 = l1 ? s67 : s45;
-    const uint32_t asel = l2 ? s47 : s03;
-    // back = 16 - 2 k (a lane without a hit: k = 0, the end of its group)
-    uint32_t back = l0 ? 14u : 16u;
-    back = l1 ? back - 4u : back;
-    back = l2 ? back - 8u : back;
-#endif
-    *any_out = any;
-    *asel_out = asel;
-    *back_out = back;
+    // The first probe that equals the key wins: the probes are looked at from the last to the first and every hit overrides what
+    // the later ones left -- eight compares, sixteen selects and no lane-mask arithmetic at all.  (Rounds 3-4 built one-hot "first hit" masks with a chain of
+    // scalar and-nots and selected through them: fourteen selects, seventeen scalar instructions.  Scalar instructions of a wave are
+    // latency of that wave: without them 3.60 -> 3.54 ms, Best 5.54 -> 5.44; a tree of ten selects with nine scalar ORs MORE was slower,
+    // 3.63.  DESIGN.md section 5.)
+    uint32_t asel_o = st.a0, back_o = 0;  // (back = 0: no hit; a hit at probe i: 16 - 2 i)
+#define MS_STEP(T, A, OFF)                 \
+    {                                      \
+        const bool h_ = st.T == st.probe;  \
+        asel_o = h_ ? st.A : asel_o;          \
+        back_o = h_ ? OFF : back_o;          \
+    }
+    MS_STEP(t7, a7, 2u) MS_STEP(t6, a6, 4u) MS_STEP(t5, a5, 6u) MS_STEP(t4, a4, 8u)
+    MS_STEP(t3, a3, 10u) MS_STEP(t2, a2, 12u) MS_STEP(t1, a1, 14u) MS_STEP(t0, a0, 16u)
+#undef MS_STEP
+    *any_out = __builtin_amdgcn_ballot_w64(back_o != 0);
+    *asel_out = asel_o;
+    *back_out = back_o ? back_o : 16u;  // (a lane without a hit left at the end of its group)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1078,7 +1046,13 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
 // ---------------------------------------------------------------------------------------------
 #define MF_ADD(F, A, REG, HALF) \
     "v_add_u32_sdwa %[" F A "], " REG ", %[" F "bb] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" HALF " src1_sel:DWORD\n\t"
-#define MF_CMP(F, N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
+#ifndef MI355_STEP_WAITS
+#define MI355_STEP_WAITS 2  // waits per group of eight answers: 8 = one in front of every compare, 2 = after four and after eight, 1 = one for
+                            // all (a wait is an instruction of the wave: 3.50 / 3.485 / 3.478 / 3.484 ms with 8 / 4 / 2 / 1)
+#endif
+#define MF_CMPW(F, N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
+#define MF_CMPN(F, N, T) "v_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
+#define MF_CMP(F, N, T) MF_CMPW(F, N, T)
 #define MF_ISSUE8(F, R0, R1, R2, R3)                                                                                 \
     MF_ADD(F, "a0", R3, "WORD_1") MF_ADD(F, "a1", R3, "WORD_0") MF_ADD(F, "a2", R2, "WORD_1") MF_ADD(F, "a3", R2, "WORD_0") \
     MF_ADD(F, "a4", R1, "WORD_1") MF_ADD(F, "a5", R1, "WORD_0") MF_ADD(F, "a6", R0, "WORD_1") MF_ADD(F, "a7", R0, "WORD_0") \
@@ -1087,11 +1061,31 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     "ds_read_u16 %[" F "t6], %[" F "a6]\n\tds_read_u16 %[" F "t7], %[" F "a7]\n\t"                                       \
     "v_add_u32_e32 %[" F "offb], -16, %[" F "offb]\n\t"
 // the eight answers of a fibre in turn, then window and entries left; N0 = reads of the other fibre still behind them
+#if MI355_STEP_WAITS == 8
 #define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
     MF_CMP(F, N7, "t0") MF_CMP(F, N6, "t1") MF_CMP(F, N5, "t2") MF_CMP(F, N4, "t3")                                \
     MF_CMP(F, N3, "t4") MF_CMP(F, N2, "t5") MF_CMP(F, N1, "t6") MF_CMP(F, N0, "t7")                                \
     "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
     "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+#elif MI355_STEP_WAITS == 4
+#define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
+    MF_CMPW(F, N6, "t0") MF_CMPN(F, N6, "t1") MF_CMPW(F, N4, "t2") MF_CMPN(F, N4, "t3")                            \
+    MF_CMPW(F, N2, "t4") MF_CMPN(F, N2, "t5") MF_CMPW(F, N0, "t6") MF_CMPN(F, N0, "t7")                            \
+    "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
+    "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+#elif MI355_STEP_WAITS == 2
+#define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
+    MF_CMPW(F, N4, "t0") MF_CMPN(F, N4, "t1") MF_CMPN(F, N4, "t2") MF_CMPN(F, N4, "t3")                            \
+    MF_CMPW(F, N0, "t4") MF_CMPN(F, N0, "t5") MF_CMPN(F, N0, "t6") MF_CMPN(F, N0, "t7")                            \
+    "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
+    "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+#else
+#define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
+    MF_CMPW(F, N0, "t0") MF_CMPN(F, N0, "t1") MF_CMPN(F, N0, "t2") MF_CMPN(F, N0, "t3")                            \
+    MF_CMPN(F, N0, "t4") MF_CMPN(F, N0, "t5") MF_CMPN(F, N0, "t6") MF_CMPN(F, N0, "t7")                            \
+    "v_cmpx_ge_u32_e32 vcc, %[" F "a7], %[" F "lowa]\n\t"                                                         \
+    "v_cmpx_ge_i32_e32 vcc, %[" F "offb], %[" F "endb]\n\t"
+#endif
 // (addresses and answers are written before they are read by every lane that walks: plain outputs, so none of a fibre's
 // sixteen stays live between its service and its next step block)
 #define MF_OPS(F, S)                                                                                                        \
@@ -1288,7 +1282,6 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unordered |= (valid && j > ob && before >= raw) ? 1u : 0u;
         *last_out = (uint32_t)__builtin_amdgcn_readlane((int)raw, 63);
         (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
-        st.done = ~st.walk;
         *srel_out = srel;
         return valid;
     };
@@ -1359,7 +1352,10 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 M2_T(12)
                 sx.walk = cx;
                 sy.walk = cy;
-                const uint64_t dx = wx & ~cx, dy = wy & ~cy;
+                // (the lanes that left the block, as scalar instructions: left to itself the compiler takes the second fibre's masks
+                // for lane values -- two moves, two bit-selects, a 64-bit compare and two read-first-lanes per round)
+                uint64_t dx, dy;
+                asm("s_andn2_b64 %0, %2, %3\n\ts_andn2_b64 %1, %4, %5" : "=&s"(dx), "=&s"(dy) : "s"(wx), "s"(cx), "s"(wy), "s"(cy) : "scc");
                 if (dx) settle(run1, sx, dx);
                 if (dy) settle(run1, sy, dy);
                 M2_T(9)

@@ -597,7 +597,7 @@ struct SwG {
     uint32_t prel, maxlen, p16[4], bm1, bestd, low;
     uint32_t offb2, endb2;                   // the segment in the previous epoch's bucket (none: offb2 < endb2)
     uint32_t seg0, vbase, mq;                // HAS_Q: offset of the segment's first entry, candidates of the segment before
-    lane_flag walk, done, in_prev, hq;
+    lane_flag walk, hq;
     lane_flag has2;  // a segment in the previous epoch's bucket is still to come
 };
 
@@ -615,7 +615,6 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.mq = 0;
     s.vbase = 0;
     s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
-    s.done = lf_of(false);
     s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = s.a5 = s.a6 = s.a7 = tbase;
     s.t0 = s.t1 = s.t2 = s.t3 = s.t4 = s.t5 = s.t6 = s.t7 = 0;
     const bool search = prel + 2 < nrel && checks > 0;
@@ -630,7 +629,6 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     const bool own = n1 > 0;
     s.offb = own ? 2 * (SW_OWN + j - 1) + 8 : s.offb2;
     s.endb = own ? s.offb + 2 - 2 * n1 : s.endb2;
-    s.in_prev = lf_of(!own);
     s.has2 = lf_of(own) & lf_of(n2 > 0);
     s.seg0 = s.offb;
     s.bb2 = tbase + ((own ? bias : 0u) << W::SH);
@@ -697,7 +695,6 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     // (positions fall along a segment, so the hit's own address tells), is no hit
     // (one comparison per ballot: a ballot of `a && b` makes the compiler turn a lane mask into 0 / 1 values and back)
     const lane_flag hit = dany & lf_of((int32_t)ho >= (int32_t)s.endb) & lf_of(asel >= s.lowa2);  // matching.rs:102-106,127,141-143
-    lane_flag rend = lf_and_not(dropped, hit);  // the segment is used up, or its next candidate is out of reach
     // get_match_length (matching.rs:67-72) against the 16 bytes of P kept in registers
     const uint32_t cpos = ((asel - tbase) >> W::SH) - s.bm1;
     uint32_t q[4];
@@ -776,13 +773,13 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     s.probe = lf_me(imp) ? pr : s.probe;
     s.offb = lf_me(hit) ? ho - 2 : s.offb;
     const lane_flag more = lf_of((int32_t)s.offb >= (int32_t)s.endb);
-    const lane_flag hgo = lf_and_not(hit, full);
-    rend = rend | lf_and_not(hgo, more);
-    const lane_flag resume = hgo & more;
-    lane_flag sw = lf_of(false);
-    if (lf_any(rend)) {
-        // end of the own epoch's segment: on to the previous epoch's bucket, if the budget reaches it
-        sw = rend & s.has2;
+    // A settled lane goes on in its segment (a hit that is not a full match, with a candidate left), or its segment is used up --
+    // then on to the previous epoch's bucket if the budget reaches it (`has2`), else it is finished --, or its match is full and it
+    // is finished.  (Few masks on purpose, and no branch around the move: every scalar instruction of the service is latency of
+    // the wave)
+    const lane_flag resume = lf_and_not(hit & more, full);
+    const lane_flag sw = lf_and_not(lf_and_not(dropped, resume), full) & s.has2;
+    if (lf_any(sw)) {  // (measured without the branch: 3.44 against 3.41 ms)
         if (HAS_Q) {
             s.vbase += lf_me(sw) ? ((s.seg0 - s.endb) >> 1) + 1 : 0u;
             s.seg0 = lf_me(sw) ? s.offb2 : s.seg0;
@@ -790,11 +787,11 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
         s.offb = lf_me(sw) ? s.offb2 : s.offb;
         s.endb = lf_me(sw) ? s.endb2 : s.endb;
         s.bb2 = lf_me(sw) ? tbase + (s.bm1 << W::SH) : s.bb2;
-        s.in_prev = s.in_prev | sw;
         s.has2 = lf_and_not(s.has2, sw);
     }
-    s.done = s.done | full | lf_and_not(rend, sw);
-    s.walk = lf_and_not(s.walk | resume | sw, s.done);
+    // (the lanes that go on: those that still walk -- none of them was settled here -- and of the settled ones those with a
+    // candidate left in their segment or a second segment to move to.  No "done" mask is kept.)
+    s.walk = s.walk | resume | sw;
 }
 
 template <bool HAS_Q>

@@ -143,7 +143,6 @@ void stage_match(Sim& s) {
                     pw.np = (uint32_t)prevS.size();
                     pw.nc = (uint32_t)curS.size();
                     (void)swg_setup(ln, pw, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
-                    ln.done = lf_not(ln.walk);
                     const uint32_t width = (j & 4) ? 8u : 4u;  // (groups of four and of eight steps)
                     lane_flag dropped = (j % 3) ? swg_first(ln, pw, width) : lf_of(false);  // (with and without the short cut)
                     int d = dropped ? 0 : -1;
