@@ -707,7 +707,9 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     const uint32_t bh = b2 < b3 ? b2 : b3;
     bits = bits < bh ? bits : bh;
     uint32_t len = (bits < 128u ? bits : 128u) >> 3;
-    const lane_flag lng = hit & lf_of(len == 16) & lf_of(s.maxlen > 16);
+    // (a lane whose sixteen bytes are all there is -- maxlen <= 16, the end of the input -- comes along and leaves the loop at once:
+    // asking for maxlen > 16 here was two vector and two scalar instructions per service)
+    const lane_flag lng = hit & lf_of(len == 16);
     if (lf_any(lng)) {
         // A candidate ONE byte back matches for as long as the position's bytes repeat the candidate's first one
         // (data[c + k] == data[c + k + 1] for every k below the length): when that is so for every lane that goes on --
