@@ -596,7 +596,8 @@ struct SwG {
     uint32_t a0, a1, a2, a3, a4, a5, a6, a7, t0, t1, t2, t3, t4, t5, t6, t7;
     uint32_t prel, maxlen, p16[4], bm1, bestd, low;
     uint32_t offb2, endb2;                   // the segment in the previous epoch's bucket (none: offb2 < endb2)
-    uint32_t seg0, vbase, mq;                // HAS_Q: offset of the segment's first entry, candidates of the segment before
+    uint32_t hoq, hoq2, mq;                  // HAS_Q: the entry offset below which a hit lies beyond the quarter budget, in the
+                                             // lane's segment and in its second one (both known at set-up)
     lane_flag walk, hq;
     lane_flag has2;  // a segment in the previous epoch's bucket is still to come
 };
@@ -613,7 +614,6 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.bm1 = 0;
     s.bestd = 0;
     s.mq = 0;
-    s.vbase = 0;
     s.hq = lf_of(HAS_Q && checks_q == 0);  // a quarter budget of zero iterations: empty result
     s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = s.a5 = s.a6 = s.a7 = tbase;
     s.t0 = s.t1 = s.t2 = s.t3 = s.t4 = s.t5 = s.t6 = s.t7 = 0;
@@ -630,7 +630,12 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.offb = own ? 2 * (SW_OWN + j - 1) + 8 : s.offb2;
     s.endb = own ? s.offb + 2 - 2 * n1 : s.endb2;
     s.has2 = lf_of(own) & lf_of(n2 > 0);
-    s.seg0 = s.offb;
+    if (HAS_Q) {
+        // rank of the entry at offset ho = (candidates of the segment before) + (seg0 - ho) / 2 + 1; it exceeds the quarter budget
+        // exactly when ho < seg0 - 2 (checks_q - before - 1): one compare per service instead of the rank's arithmetic
+        s.hoq = s.offb - 2u * (checks_q - 1u);
+        s.hoq2 = s.offb2 - 2u * (checks_q - n1 - 1u);  // (the second segment, if there is one, has the n1 of the first before it)
+    }
     s.bb2 = tbase + ((own ? bias : 0u) << W::SH);
     s.lowa2 = tbase + (s.low << W::SH);
     w.load16(prel, s.p16);
@@ -759,8 +764,7 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     }
     len = len < s.maxlen ? len : s.maxlen;
     if (HAS_Q) {  // lz77.rs:351-355: the state after max_hash_checks >> 2 iterations, taken before the first later hit counts
-        const uint32_t rank = s.vbase + ((s.seg0 - ho) >> 1) + 1;
-        const lane_flag cap = lf_and_not(hit, s.hq) & lf_of(rank > checks_q);
+        const lane_flag cap = lf_and_not(hit, s.hq) & lf_of((int32_t)ho < (int32_t)s.hoq);
         s.mq = lf_me(cap) ? m_pack(s.bestd ? s.bm1 + 1 : 0, s.bestd) : s.mq;
         s.hq = s.hq | cap;
     }
@@ -782,10 +786,7 @@ MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t ch
     const lane_flag resume = lf_and_not(hit & more, full);
     const lane_flag sw = lf_and_not(lf_and_not(dropped, resume), full) & s.has2;
     if (lf_any(sw)) {  // (measured without the branch: 3.44 against 3.41 ms)
-        if (HAS_Q) {
-            s.vbase += lf_me(sw) ? ((s.seg0 - s.endb) >> 1) + 1 : 0u;
-            s.seg0 = lf_me(sw) ? s.offb2 : s.seg0;
-        }
+        if (HAS_Q) s.hoq = lf_me(sw) ? s.hoq2 : s.hoq;
         s.offb = lf_me(sw) ? s.offb2 : s.offb;
         s.endb = lf_me(sw) ? s.endb2 : s.endb;
         s.bb2 = lf_me(sw) ? tbase + (s.bm1 << W::SH) : s.bb2;
