@@ -1098,12 +1098,6 @@ template <bool HAS_Q>
 __device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_t* sb8, uint64_t walkx, uint64_t walky,
                                               uint64_t* stillx, uint64_t* stilly) {
     uint64_t save, cx, cy;
-    {   // (the base must sit in scalar registers; under register pressure the compiler has kept it in vector ones)
-        const uint64_t v = (uint64_t)(uintptr_t)sb8;
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        sb8 = (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-    }
 #define MF_ONE(F, W, C, RA, RB, R0, R1, R2, R3, R4, R5, R6, R7)                           \
         "s_mov_b64 exec, %[" W "]\n\t"                                                      \
         "global_load_dwordx4 " RA ", %[" F "offb], %[sb] offset:-14\n\t"                    \
@@ -1305,6 +1299,14 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // The walk of the workgroup's batches, in two instantiations: RUN1 is the service with the one-sided long compare
     // (stages.h swg_service) for epochs that k_sort found to consist of runs of one byte -- zero fill and the like, where
     // every position's first candidate is its neighbour and matches to the end -- and costs the other epochs nothing.
+    // (the step block's base of the sorted arrays, made scalar once: inside the loop it was two read-first-lanes per round)
+    const uint16_t* sb8u;
+    {
+        const uint64_t v = (uint64_t)(uintptr_t)(sbase - 4);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        sb8u = (const uint16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    }
     auto walk_all = [&](auto run1) {
         constexpr bool RUN1 = decltype(run1)::value;
         uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
@@ -1348,7 +1350,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 M2_CNT(1, 1)
                 M2_CNT(7, __popcll(wx) + __popcll(wy))
                 uint64_t cx, cy;
-                ms_steps_dual(sx, sy, sbase - 4, wx, wy, &cx, &cy);
+                ms_steps_dual(sx, sy, sb8u, wx, wy, &cx, &cy);
                 M2_T(12)
                 sx.walk = cx;
                 sy.walk = cy;
