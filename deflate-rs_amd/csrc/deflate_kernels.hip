@@ -115,6 +115,9 @@ struct DevState {
 __device__ __forceinline__ bool spec_failed(const DevScalars* sc) { return reinterpret_cast<const DevState*>(sc)->spec_bad != 0; }
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
+#ifndef MI355_ADV_STRAIGHT
+#define MI355_ADV_STRAIGHT 1  // (k_adv 0.22 -> 0.14 ms: parse 0.577 -> 0.494 ms)
+#endif
 #ifndef MI355_FAN
 #define MI355_FAN 16  // (measured: parse 0.789 / 0.770 / 0.767 / 0.778 / 0.811 ms with 4 / 8 / 16 / 32 / 64 -- more, shorter launches win)
 #endif
@@ -1578,9 +1581,47 @@ __global__ __launch_bounds__(256) void k_adv(uint32_t n, const uint32_t* __restr
     const uint32_t one = sg.m == 1 ? rel_end(sg, t0, 0) : 0u;  // without flush points: one end for all
     TileM m{sM}, mq{useq ? sQ : sM};
     uint16_t a[4] = {0, 0, 0, 0};
+#if MI355_ADV_STRAIGHT
+    // The lazy step without its loop (one end for all, full-budget table only): "a+1 beats a" is a property of the
+    // position -- len(M[a]) < lazy_lt, a+1 has a hash byte, len(M[a+1]) > len(M[a]) -- so the deferral chain from j is
+    // the run of such positions starting at j.  Eight of these bits from the lane's own nine entries cover the chains
+    // of its four positions unless one is longer than four deferrals (then the loop below takes that lane).
+    bool loop_it = !(cfg.mode == MODE_LAZY && !cfg.use_quarter && sg.m == 1);
+    if (!loop_it) {
+        const uint4 e0 = *reinterpret_cast<const uint4*>(sM + r0), e1 = *reinterpret_cast<const uint4*>(sM + r0 + 4);
+        const uint32_t e[9] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, sM[r0 + 8]};
+        uint32_t ups = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t L = m_len(e[i]), L2 = m_len(e[i + 1]);
+            ups |= (uint32_t)(L < cfg.lazy_lt && L2 > L) << i;
+        }
+        // a + 1 + 2 < one  for a = r0 + i:  i < one - r0 - 3
+        const uint32_t room = one > r0 + 3 ? one - r0 - 3 : 0u;
+        ups &= room >= 8 ? 0xFFu : (1u << room) - 1u;
+        uint32_t runs[4];
+        bool deep = false;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            runs[q] = (uint32_t)__builtin_ctz(~(ups >> q));
+            deep = deep || q + runs[q] >= 8;
+        }
+        if (!deep) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t L = m_len(e[q]);
+                const bool ok = r0 + q + 2 < one && L >= MIN_MATCH && !match_too_far(L, m_dist(e[q]));
+                const uint32_t Le = m_len(sM[r0 + q + runs[q]]);
+                a[q] = r0 + q < left ? (uint16_t)(ok ? (runs[q] + Le) | (runs[q] << ADV_RUN_SHIFT) : 1u) : (uint16_t)0;
+            }
+        }
+        loop_it = deep;
+    }
+    if (loop_it)
+#endif
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++)
-        if (r0 + q < left) a[q] = (uint16_t)parse_step(m, mq, r0 + q, sg.m == 1 ? one : rel_end(sg, t0, r0 + q), cfg).adv;
+        if (r0 + q < left) a[q] = (uint16_t)adv_pack(parse_step(m, mq, r0 + q, sg.m == 1 ? one : rel_end(sg, t0, r0 + q), cfg));
     if (r0 + 4 <= left) {
         uint2 v = make_uint2((uint32_t)a[0] | ((uint32_t)a[1] << 16), (uint32_t)a[2] | ((uint32_t)a[3] << 16));
         *reinterpret_cast<uint2*>(adv + t0 + r0) = v;  // adv is 256-byte aligned, r0 a multiple of 4
@@ -1609,7 +1650,7 @@ __device__ __forceinline__ void seg_sweep(const uint16_t* __restrict__ adv, uint
         if ((uint32_t)c >= len) continue;
         uint32_t r = (uint32_t)c + lane;  // segment-relative position
         bool valid = r < len;
-        uint32_t t = valid ? r + av[q] : 0;
+        uint32_t t = valid ? r + (av[q] & ADV_LEN_MASK) : 0;  // (k_adv's entries: adv_pack)
         // one word per lane: bit 31 set = resolved, the low bits the exit; clear = the lane (of this chunk) it jumps to, times 4.
         // A round of pointer jumping is then ONE cross-lane read -- the word of the target is either its answer or the
         // lane two jumps on -- where value, flag and target were three (the kernel's time was their trips through the LDS
@@ -1854,8 +1895,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     }
     wave_lds_fence();
     for (uint32_t r = lane; r < len; r += 64) {  // two steps, or one that leaves the segment
-        const uint32_t t = r + A[r];
-        P[r] = (uint16_t)((t < len ? t + A[t] : t) - r);
+        const uint32_t t = r + (A[r] & ADV_LEN_MASK);  // (k_adv's entries: adv_pack)
+        P[r] = (uint16_t)((t < len ? t + (A[t] & ADV_LEN_MASK) : t) - r);
     }
     wave_lds_fence();
     // four steps, in place and left to right: an entry reads entries to its right -- those of its own 64 before
@@ -1885,7 +1926,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                 if (t >= w0) break;
                 j = t;
             }
-            while (j < w0) j += A[j];
+            while (j < w0) j += A[j] & ADV_LEN_MASK;
             E0[k] = (uint32_t)(a + j);
         } else {
             const uint64_t e = MODE == 2 ? (uint64_t)given : (uint64_t)E0[k];
@@ -1916,35 +1957,41 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         const bool have = idx < np;
         uint32_t nl[4], tm[4], ntok = 0;
         uint32_t jp[4];  // (relative to the segment, like the tables below)
-        // The four positions of a lane come out of the jumps in LDS, so the table entries all four steps will look at first
-        // -- M at the position and at the one behind it, where the lazy step looks (lz77.rs:351-355) -- are fetched together:
-        // taken one parse_step after the other they were a dozen memory latencies in a row.
+        // What a step did is read off the entry k_adv filed for it (adv_pack: its length, its deferrals, the table of its
+        // match) instead of being worked out again from M: a length of 1 is a literal; otherwise the deferrals are literals
+        // and the match is the rest of the length at the distance of the entry behind them.  A lane's four positions come
+        // out of the lengths in LDS, so its four distances and first literal bytes are fetched together, one memory
+        // latency for the round (worked out step by step -- M at the position, behind it, and on while the chain went on --
+        // they were several in a row, under divergent branches).  MODE_RLE's distance is 1 (rle.rs:46-69).
         uint32_t rel = have ? (uint32_t)P[idx] : len;
-        uint32_t v0[4], v1[4], u1[4];
+        uint32_t ent[4], lb[4], ad[4];
+        const bool rle = cfg.mode == MODE_RLE;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const bool on = rel < len;
             jp[q] = on ? rel : len;
-            v0[q] = v1[q] = u1[q] = 0;
+            ent[q] = 1u << 16;
+            lb[q] = ad[q] = 0;
             if (on) {
-                v0[q] = Ms[rel];
-                v1[q] = Ms[rel + 1];  // (the tables are padded: the entry behind the last position exists)
-                if (Mq) u1[q] = Mqs[rel + 1];
-                rel += A[rel];
+                const uint32_t w = A[rel];
+                ad[q] = w;
+                if (!rle) ent[q] = ((w >> ADV_FROMQ_SHIFT) ? Mqs : Ms)[rel + ((w >> ADV_RUN_SHIFT) & ADV_RUN_MASK)];  // (padded tables)
+                lb[q] = ins[rel];
+                rel += w & ADV_LEN_MASK;
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            nl[q] = 0;
-            tm[q] = 0;
-            const uint32_t j = jp[q];
-            if (j < len) {
-                const NearM m{Ms, j, v0[q], v1[q]}, mq{Mqs, j, v0[q], Mq ? u1[q] : v1[q]};
+            const uint32_t j = jp[q], adv_j = ad[q] & ADV_LEN_MASK, run = (ad[q] >> ADV_RUN_SHIFT) & ADV_RUN_MASK;
+            nl[q] = adv_j == 1 ? 1u : run;
+            tm[q] = adv_j > 1 ? tok_match(adv_j - run, m_dist(ent[q])) : 0u;  // (never 0 for a match: dist >= 1)
+            if (run == ADV_RUN_MANY) {  // more deferrals in a row than the entry holds: the step itself
+                const TileM m{Ms}, mq{Mqs};
                 const Step st = parse_step(m, mq, j, sg.m == 1 ? one : rel_end(sg, sbase, j), cfg);
                 nl[q] = st.nlit;
-                tm[q] = st.mlen ? tok_match(st.mlen, st.mdist) : 0u;  // (never 0 for a match: dist >= 1)
-                ntok += st.nlit + (st.mlen ? 1u : 0u);
+                tm[q] = tok_match(st.mlen, st.mdist);
             }
+            ntok += nl[q] + (tm[q] ? 1u : 0u);
         }
         uint32_t incl = ntok;
 #pragma unroll
@@ -1956,7 +2003,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         uint32_t* o = out + running + (incl - ntok);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            for (uint32_t x = 0; x < nl[q]; x++) o[x] = tok_literal(ins[jp[q] + x]);
+            if (nl[q]) o[0] = tok_literal(lb[q]);
+            for (uint32_t x = 1; x < nl[q]; x++) o[x] = tok_literal(ins[jp[q] + x]);
             o += nl[q];
             if (tm[q]) *o++ = tm[q];
         }

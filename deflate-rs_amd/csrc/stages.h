@@ -851,7 +851,16 @@ struct Step {
     uint32_t mlen;   // 0 = no match in this step; else match at j+nlit
     uint32_t mdist;
     uint32_t adv;    // next restart position - j  (1..MAX_JUMP)
+    uint32_t fromq;  // the match's entry is the quarter-budget table's (lz77.rs:351-355)
 };
+// A step as k_adv files it for k_emit, 16 bits: the length of the step (1 .. 255 + 258) in bits 0-9, the literals in front of
+// its match (the deferrals) in bits 10-14 -- 31: more than 30, not kept -- and in bit 15 which table the match's entry is in.
+// With these the replay of a step is one read (the distance at j + deferrals) instead of the step worked out again.
+constexpr uint32_t ADV_LEN_MASK = 1023, ADV_RUN_SHIFT = 10, ADV_RUN_MASK = 31, ADV_RUN_MANY = 31, ADV_FROMQ_SHIFT = 15;
+MI355_HD uint32_t adv_pack(const Step& s) {
+    const uint32_t run = s.mlen ? (s.nlit < ADV_RUN_MANY ? s.nlit : ADV_RUN_MANY) : 0u;
+    return s.adv | (run << ADV_RUN_SHIFT) | (s.fromq << ADV_FROMQ_SHIFT);
+}
 
 // lz77.rs:275-278
 MI355_HD bool match_too_far(uint32_t len, uint32_t dist) { return len == MIN_MATCH && dist > TOO_FAR; }
@@ -874,6 +883,7 @@ MI355_HD Step parse_step(const MT& M, const MT& Mq, I j, I n, const ParseCfg& cf
     s.mlen = 0;
     s.mdist = 0;
     s.adv = 1;
+    s.fromq = 0;
     if (cfg.mode == MODE_RLE) {  // rle.rs:46-69
         uint32_t r = (uint32_t)M(j);
         if (r >= MIN_MATCH) {
@@ -906,9 +916,11 @@ MI355_HD Step parse_step(const MT& M, const MT& Mq, I j, I n, const ParseCfg& cf
     for (;;) {
         if (L >= cfg.lazy_lt) break;   // ignore_next (lz77.rs:374-377,380-386)
         if (a + 1 + 2 >= n) break;     // a+1 has no hash byte (lz77.rs:442-468)
-        uint32_t m2 = (cfg.use_quarter && L >= 32) ? (uint32_t)Mq(a + 1) : (uint32_t)M(a + 1);  // lz77.rs:351-355
+        const bool quarter = cfg.use_quarter && L >= 32;  // lz77.rs:351-355
+        uint32_t m2 = quarter ? (uint32_t)Mq(a + 1) : (uint32_t)M(a + 1);
         uint32_t L2 = m_len(m2);
         if (L2 > L) {                  // strictly better (matching.rs:161); cannot be too_far (L2 >= 4)
+            s.fromq = quarter ? 1u : 0u;
             s.nlit++;                  // lz77.rs:430-434: the previous byte becomes a literal
             a++;
             L = L2;
