@@ -118,6 +118,9 @@ constexpr uint32_t SEG = 1024;  // positions per level-0 segment
 #ifndef MI355_ADV_STRAIGHT
 #define MI355_ADV_STRAIGHT 1  // (k_adv 0.22 -> 0.14 ms: parse 0.577 -> 0.494 ms)
 #endif
+#ifndef MI355_STEPS_IN_EMIT
+#define MI355_STEPS_IN_EMIT 1
+#endif
 #ifndef MI355_FAN
 #define MI355_FAN 16  // (measured: parse 0.789 / 0.770 / 0.767 / 0.778 / 0.811 ms with 4 / 8 / 16 / 32 / 64 -- more, shorter launches win)
 #endif
@@ -1847,6 +1850,7 @@ constexpr uint32_t SPEC_W = 128;  // (measured with the repair in place, parse s
                                   // the Silesia-like mix 1.64 / 1.33 / 1.40 ms -- at 64 a thousand of its entries need the repair)
 constexpr uint32_t FIX_MAX = 1024;  // listed segments the repair takes on (more: the data is periodic at large, the exact parse is due)
 constexpr uint32_t FIX_HOPS = 24;
+constexpr uint32_t STEP_CHUNKS = 5;  // k_emit's steps from M: rounds of 256 positions of a wave
 struct SpecFix {
     uint32_t* list;          // segments whose entry is not the exit of the segment before, each with that exit
     uint32_t* badmap;        // the same as a bit per segment
@@ -1861,8 +1865,12 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                                               uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0, uint32_t seg0) {
     constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
-    __shared__ uint16_t s_adv[4][REG];
-    __shared__ uint16_t s_pp[4][REG];
+    // (rows of STEP_CHUNKS * 256 + 8 entries: the steps worked out here -- adv == nullptr -- go through 256 positions at a time
+    // and look eight entries beyond a position)
+    constexpr uint32_t ROW = STEP_CHUNKS * 256 + 8;
+    static_assert(REG + 12 <= STEP_CHUNKS * 256 && ROW % 4 == 0, "the chunks cover the region and what a step looks at behind it");
+    __shared__ __attribute__((aligned(8))) uint16_t s_adv[4][ROW];
+    __shared__ __attribute__((aligned(8))) uint16_t s_pp[4][ROW];
     __shared__ uint32_t s_np[4], s_exit[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
@@ -1885,13 +1893,78 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
     const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
     const uint32_t len = (uint32_t)(b - a);
-    {   // (fetched together: a load per round of a loop is a memory latency per round)
+    if (adv != nullptr) {   // (fetched together: a load per round of a loop is a memory latency per round)
         uint16_t av[REG / 64];
 #pragma unroll
         for (uint32_t q = 0; q < REG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
 #pragma unroll
         for (uint32_t q = 0; q < REG / 64; q++)
             if (q * 64 + lane < len) A[q * 64 + lane] = av[q];
+    } else {
+        // The steps worked out here, from M (k_adv's lazy step without its loop; one end of the data, the full-budget table
+        // only -- the host sees to that): k_adv read M and wrote two bytes a position for this kernel to read again, a
+        // third of the parse stage's traffic.  (a) the wave's entries, sixteen bytes a lane at a time: their lengths go to
+        // LDS (where P will be), "too far" (lz77.rs:275-278), the one thing a step wants of a distance, into a bit each;
+        const uint32_t* const Mf = M + (uint64_t)pos0 + a;
+        const uint64_t there = (uint64_t)n_total + 64 - ((uint64_t)pos0 + a);  // (the table is padded by 64 entries)
+        const uint32_t avail = there > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)there;
+        const uint32_t endd = rel_end(sg, (uint64_t)pos0 + a, 0);
+        const bool al = (reinterpret_cast<uintptr_t>(Mf) & 15) == 0;  // (a segment starts at a multiple of 128 entries of a 256-byte aligned table)
+        uint32_t tf = 0;
+        uint4 ev[STEP_CHUNKS];
+#pragma unroll
+        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
+            const uint32_t r0 = 4 * (lane + 64 * c);
+            ev[c] = make_uint4(0, 0, 0, 0);
+            if (r0 < len + 12) {
+                if (al && r0 + 4 <= avail) {
+                    ev[c] = *reinterpret_cast<const uint4*>(Mf + r0);
+                } else {
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (uint32_t i = 0; i < 4; i++)
+                        if (r0 + i < avail) t[i] = Mf[r0 + i];
+                    ev[c] = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
+            const uint32_t r0 = 4 * (lane + 64 * c);
+            const uint32_t e[4] = {ev[c].x, ev[c].y, ev[c].z, ev[c].w};
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) tf |= (uint32_t)match_too_far(m_len(e[i]), m_dist(e[i])) << (4 * c + i);
+            *reinterpret_cast<uint2*>(P + r0) = make_uint2(m_len(e[0]) | (e[1] << 16), m_len(e[2]) | (e[3] << 16));
+        }
+        wave_lds_fence();
+        // (b) the steps of four positions from nine lengths (k_adv); a chain of more than four deferrals runs the step itself
+        const bool lazy = cfg.mode == MODE_LAZY;
+#pragma unroll
+        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
+            const uint32_t r0 = 4 * (lane + 64 * c);
+            if (r0 >= len) continue;
+            const uint2 w0 = *reinterpret_cast<const uint2*>(P + r0), w1 = *reinterpret_cast<const uint2*>(P + r0 + 4);
+            const uint32_t L[9] = {w0.x & 0xffffu, w0.x >> 16, w0.y & 0xffffu, w0.y >> 16,
+                                   w1.x & 0xffffu, w1.x >> 16, w1.y & 0xffffu, w1.y >> 16, (uint32_t)P[r0 + 8]};
+            uint32_t ups = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) ups |= (uint32_t)(L[i] < cfg.lazy_lt && L[i + 1] > L[i]) << i;
+            const uint32_t room = endd > r0 + 3 ? endd - r0 - 3 : 0u;  // a + 1 + 2 < endd  for a = r0 + i:  i < endd - r0 - 3
+            ups &= room >= 8 ? 0xFFu : (1u << room) - 1u;
+            ups = lazy ? ups : 0u;  // lz77.rs:512-534: the greedy step takes what it finds
+            uint32_t st4[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t run = (uint32_t)__builtin_ctz(~(ups >> q));
+                const bool ok = r0 + q + 2 < endd && L[q] >= MIN_MATCH && !((tf >> (4 * c + q)) & 1u);
+                const uint32_t Le = P[r0 + q + run];  // (q + run <= 8)
+                st4[q] = ok ? (run + Le) | (run << ADV_RUN_SHIFT) : 1u;
+                if (ok && q + run >= 8) {
+                    const TileM mf{Mf};
+                    st4[q] = adv_pack(parse_step(mf, mf, r0 + q, endd, cfg));
+                }
+            }
+            *reinterpret_cast<uint2*>(A + r0) = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));
+        }
     }
     wave_lds_fence();
     for (uint32_t r = lane; r < len; r += 64) {  // two steps, or one that leaves the segment
