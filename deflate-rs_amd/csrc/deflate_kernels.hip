@@ -1653,7 +1653,11 @@ __device__ __forceinline__ void seg_sweep(const uint16_t* __restrict__ adv, uint
         if ((uint32_t)c >= len) continue;
         uint32_t r = (uint32_t)c + lane;  // segment-relative position
         bool valid = r < len;
-        uint32_t t = valid ? r + (av[q] & ADV_LEN_MASK) : 0;  // (k_adv's entries: adv_pack)
+        // (k_adv's entries: adv_pack.  The mask is taken here, behind an opaque move: left to itself the compiler masks every
+        // entry right behind its load, with a wait for that load -- sixteen memory latencies in a row again, 0.2 -> 0.4 ms)
+        uint32_t step = av[q];
+        asm volatile("" : "+v"(step));
+        uint32_t t = valid ? r + (step & ADV_LEN_MASK) : 0;
         // one word per lane: bit 31 set = resolved, the low bits the exit; clear = the lane (of this chunk) it jumps to, times 4.
         // A round of pointer jumping is then ONE cross-lane read -- the word of the target is either its answer or the
         // lane two jumps on -- where value, flag and target were three (the kernel's time was their trips through the LDS
@@ -1856,7 +1860,8 @@ struct SpecFix {
     uint32_t* badmap;        // the same as a bit per segment
     const uint32_t* n;       // how many
 };
-template <int MODE>
+// (STEPS: the wave works the restart steps out itself, from M -- adv is not read; else they come from k_adv / k_rle through adv)
+template <int MODE, bool STEPS>
 __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                               const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
                                               ParseCfg cfg, const uint16_t* __restrict__ adv,
@@ -1865,9 +1870,9 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                                               uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0, uint32_t seg0) {
     constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
-    // (rows of STEP_CHUNKS * 256 + 8 entries: the steps worked out here -- adv == nullptr -- go through 256 positions at a time
+    // (rows of STEP_CHUNKS * 256 + 8 entries: the steps worked out here -- STEPS -- go through 256 positions at a time
     // and look eight entries beyond a position)
-    constexpr uint32_t ROW = STEP_CHUNKS * 256 + 8;
+    constexpr uint32_t ROW = STEPS ? STEP_CHUNKS * 256 + 8 : REG;
     static_assert(REG + 12 <= STEP_CHUNKS * 256 && ROW % 4 == 0, "the chunks cover the region and what a step looks at behind it");
     __shared__ __attribute__((aligned(8))) uint16_t s_adv[4][ROW];
     __shared__ __attribute__((aligned(8))) uint16_t s_pp[4][ROW];
@@ -1893,7 +1898,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
     const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
     const uint32_t len = (uint32_t)(b - a);
-    if (adv != nullptr) {   // (fetched together: a load per round of a loop is a memory latency per round)
+    if (!STEPS) {   // (fetched together: a load per round of a loop is a memory latency per round)
         uint16_t av[REG / 64];
 #pragma unroll
         for (uint32_t q = 0; q < REG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
@@ -3503,6 +3508,14 @@ __global__ void k_gzip_frame(DevScalars* sc, uint8_t* out, const uint8_t* hdr, u
 
 }  // namespace mi355
 
+// k_emit with the steps from adv, or worked out by the kernel itself when `steps` -- what goes into its adv argument -- is nullptr
+#define MI355_LAUNCH_EMIT(MODE, steps, grid, st, ...)                                                    \
+    do {                                                                                                 \
+        if (steps)                                                                                       \
+            hipLaunchKernelGGL((k_emit<MODE, false>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_emit<MODE, true>), grid, dim3(256), 0, st, __VA_ARGS__);               \
+    } while (0)
 #include "deflate_host.inc"
 #include "deflate_shard.inc"
 #include "deflate_long.inc"
