@@ -804,11 +804,21 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     const bool whole = J == WINDOW_SIZE && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && E + WINDOW_SIZE + 4 <= (uint64_t)n &&
                        !(ov.on | ov.m);
     if (whole) {
+        // (the four rounds' bytes fetched before the first is worked on: with a load at the head of each round -- the LDS
+        // atomics keep the compiler from moving it up -- a thread waited for memory four times in a row)
+        uint2 wr[WINDOW_SIZE / (8 * 1024)];
+        uint32_t nr[WINDOW_SIZE / (8 * 1024)];
 #pragma unroll
         for (uint32_t r = 0; r < WINDOW_SIZE / (8 * 1024); r++) {
             const uint32_t i = (r * 1024 + tid) * 8;
-            const uint2 w = *reinterpret_cast<const uint2*>(in + E + i);
-            const uint32_t nx = *reinterpret_cast<const uint32_t*>(in + E + i + 8);
+            wr[r] = *reinterpret_cast<const uint2*>(in + E + i);
+            nr[r] = *reinterpret_cast<const uint32_t*>(in + E + i + 8);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < WINDOW_SIZE / (8 * 1024); r++) {
+            const uint32_t i = (r * 1024 + tid) * 8;
+            const uint2 w = wr[r];
+            const uint32_t nx = nr[r];
             const uint32_t d[3] = {w.x, w.y, nx};
             uint32_t hs[8];
             // (a wave whose 512 positions lie in a run of one byte counts them with one add: 64 lanes on one counter,
