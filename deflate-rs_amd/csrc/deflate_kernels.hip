@@ -3168,16 +3168,34 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
     const uint64_t t0 = (uint64_t)tab.t0[b] + (uint64_t)part * PQ;
     const uint64_t t1 = (uint64_t)tab.t0[b] + ((part + 1) * PQ < nt ? (part + 1) * PQ : nt);
     const uint32_t lane = tid & 63, wv = tid >> 6;
+    // (a round's four tokens are fetched a round ahead, as one 16-byte load where all four exist: at the head of the round
+    // they were a memory latency per round, between two barriers)
+    auto fetch4 = [&](uint64_t tq, uint32_t* tk) {
+        if (tq + 4 <= t1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(dtok + tq);  // (dword aligned is all a global load asks for)
+            tk[0] = v.x;
+            tk[1] = v.y;
+            tk[2] = v.z;
+            tk[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) tk[q] = tq + q < t1 ? dtok[tq + q] : 0u;
+        }
+    };
+    uint32_t nxt[4];
+    fetch4(t0 + 4ull * tid, nxt);
     for (uint64_t tb = t0; tb < t1; tb += 4 * PKT) {
         uint64_t tq = tb + 4ull * tid;
         uint32_t nb4[4];
         uint64_t bits4[4];
         uint32_t mine = 0;
+        const uint32_t cur[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        if (tb + 4 * PKT < t1) fetch4(tq + 4 * PKT, nxt);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             nb4[q] = 0;
             bits4[q] = 0;
-            if (tq + q < t1) bits4[q] = token_bits(dtok[tq + q], s.llc, s.lll, s.dc, s.dl, &nb4[q]);
+            if (tq + q < t1) bits4[q] = token_bits(cur[q], s.llc, s.lll, s.dc, s.dl, &nb4[q]);
             mine += nb4[q];
         }
         uint32_t incl = mine;
