@@ -2415,16 +2415,26 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
     const uint32_t nt = tab.nt[b];
     const uint64_t t0 = (uint64_t)tab.t0[b] + (uint64_t)q * PQ;
     const uint64_t t1 = (uint64_t)tab.t0[b] + ((q + 1) * PQ < nt ? (q + 1) * PQ : nt);
-    for (uint64_t t = t0 + threadIdx.x; t < t1; t += 256) {
-        uint32_t tk = dtok[t];
-        if (tk >> 16) {
-            uint32_t c, eb, ev;
-            length_symbol(tk & 0xff, &c, &eb, &ev);
-            atomicAdd(&h[257 + c], 1u);
-            distance_symbol(tk >> 16, &c, &eb, &ev);
-            atomicAdd(&h[288 + c], 1u);
-        } else {
-            atomicAdd(&h[tk & 0xff], 1u);
+    // (eight tokens a thread fetched together: one load per round in front of its LDS atomics was a memory latency per
+    // round, thirty-one in a row -- the kernel's whole time)
+    constexpr uint32_t HB = 8;
+    for (uint64_t tb = t0 + threadIdx.x; tb < t1; tb += 256 * HB) {
+        uint32_t tks[HB];
+#pragma unroll
+        for (uint32_t k = 0; k < HB; k++) tks[k] = tb + 256 * k < t1 ? dtok[tb + 256 * k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < HB; k++) {
+            if (tb + 256 * k >= t1) break;
+            const uint32_t tk = tks[k];
+            if (tk >> 16) {
+                uint32_t c, eb, ev;
+                length_symbol(tk & 0xff, &c, &eb, &ev);
+                atomicAdd(&h[257 + c], 1u);
+                distance_symbol(tk >> 16, &c, &eb, &ev);
+                atomicAdd(&h[288 + c], 1u);
+            } else {
+                atomicAdd(&h[tk & 0xff], 1u);
+            }
         }
     }
     __syncthreads();
