@@ -954,13 +954,17 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 }
 
 #ifdef MI355_MATCH_STATS
-#define M2_CNT(i, v) m2c[i] += (v);
-#define M2_T0 unsigned long long m2t = __builtin_readcyclecounter();
-#define M2_T(i)                                                    \
-    {                                                              \
-        unsigned long long t_ = __builtin_readcyclecounter();      \
-        m2c[i] += t_ - m2t;                                        \
-        m2t = t_;                                                  \
+// (MI355_MATCH_STATS = 1: the clocks and the number of batches; 2: the counters.  Together -- and as sixteen 64-bit values --
+// they took the walk's scalar registers, the instrumented kernel spilled 60 bytes a lane and its clock shares were those of
+// another kernel.  32 bits hold a wave's totals, and differences survive the wrap.)
+#define M2_CNT(i, v) \
+    if (((MI355_MATCH_STATS) & 2) || (i) == 0) m2c[i] += (uint32_t)(v);
+#define M2_T0 uint32_t m2t = ((MI355_MATCH_STATS) & 1) ? (uint32_t)__builtin_readcyclecounter() : 0u;
+#define M2_T(i)                                                      \
+    if ((MI355_MATCH_STATS) & 1) {                                   \
+        const uint32_t t_ = (uint32_t)__builtin_readcyclecounter();  \
+        m2c[i] += t_ - m2t;                                          \
+        m2t = t_;                                                    \
     }
 #else
 #define M2_CNT(i, v)
@@ -1257,7 +1261,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint16_t* Bprev = Bown - BSTRIDE;
     TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
 #ifdef MI355_MATCH_STATS
-    unsigned long long m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     M2_T0
     uint32_t unordered = 0;
@@ -1423,7 +1427,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #ifdef MI355_MATCH_STATS
     if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], m2c[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], (unsigned long long)m2c[i]);
 #endif
 }
 

@@ -20,19 +20,28 @@ n = len(data)
 ctx = da.Context(0)
 L = da.load()
 out = (C.c_ulonglong * 16)()
-read = L.mi355_debug_match_stats if what == "match" else L.mi355_debug_sort_stats
+read = L.mi355_debug_match_stats if what.startswith("match") else L.mi355_debug_sort_stats
 for _ in range(2):  # (the second run is the one reported: the first one warms the context up)
     ctx.encode(data, lv)
     read(out, 1)
 s = list(out)
-if what == "match":
+if what == "match-counts":  # (the counters' build, run by the "match" call below)
     nb = s[0]
-    print("positions", n, "match_ms", ctx.info()["match_ms"], "batches", nb)
     print("step blocks/batch %.2f  walking lanes per block %.1f   services/batch %.2f  lanes settled per service %.1f" % (
         s[1] / nb, s[7] / max(1, s[1]), s[2] / nb, s[3] / max(1, s[2])))
+elif what == "match":
+    nb = s[0]
+    print("positions", n, "match_ms", ctx.info()["match_ms"], "batches", nb)
+    sys.stdout.flush()
+    cnt = os.path.join(os.path.dirname(LIB), "libstats_cnt.so")
+    if os.path.exists(cnt):
+        subprocess.call([sys.executable, os.path.abspath(__file__), "match-counts"] + sys.argv[2:], env=dict(os.environ, MI355_STATS_LIB=cnt))
     t = {k: s[i] for k, i in (("setup", 8), ("service", 9), ("steps", 12), ("result", 13))}
     tot = sum(t.values())
     print("clock shares: " + "  ".join("%s %.3f" % (k, v / tot) for k, v in t.items()), " cycles/batch %.0f" % (tot / nb))
+    print("(the instrumented kernel is not the product's: at the walk's limit of scalar registers its counters spill, and a clock read\n"
+          " waits for the LDS reads in flight behind the step block -- that wait lands in `steps` here and in the service's first use in the\n"
+          " product.  Until round 5's scalar-instruction work the same build read set-up 15 / service 51 / steps 34 %, 22 321 cycles a batch.)")
 else:
     names = ["hash+hist", "bucket starts", "p1 count", "p1 offsets", "p1 scatter", "p2 count", "p2 offsets", "p2 scatter"]
     s = s[:8]
