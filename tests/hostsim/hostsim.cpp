@@ -282,7 +282,36 @@ void stage_parse_hier(Sim& s, uint32_t S, uint32_t G) {
     MAcc M{s.M.data()}, Mq{s.Mq.data()};
     uint64_t n = s.n;
     s.adv.assign(n, 0);
-    for (uint64_t j = 0; j < n; j++) s.adv[j] = (uint16_t)parse_step(M, Mq, j, n, s.cfg).adv;
+    for (uint64_t j = 0; j < n; j++) {
+        const Step st = parse_step(M, Mq, j, n, s.cfg);
+        s.adv[j] = (uint16_t)st.adv;
+        // What the kernels make of a step instead of running it (reported like a path mismatch):
+        // (a) k_emit's replay reads a step off the entry k_adv files for it (adv_pack): a length of 1 is a literal, else the
+        //     deferrals are literals and the match is the rest of the length at the distance of the entry behind them
+        const uint32_t w = adv_pack(st);
+        const uint32_t len = w & ADV_LEN_MASK, run = (w >> ADV_RUN_SHIFT) & ADV_RUN_MASK, fromq = w >> ADV_FROMQ_SHIFT;
+        if (len != st.adv) s.hier_mismatch = true;
+        if (run != ADV_RUN_MANY) {
+            const uint32_t nl = len == 1 ? 1u : run;
+            uint32_t ml = 0, md = 0;
+            if (len > 1) {
+                ml = len - run;
+                md = s.cfg.mode == MODE_RLE ? 1u : m_dist(fromq ? (uint32_t)Mq(j + run) : (uint32_t)M(j + run));
+            }
+            if (nl != st.nlit || ml != st.mlen || md != st.mdist) s.hier_mismatch = true;
+        }
+        // (b) the lazy step without its loop (k_adv, k_emit): "a + 1 beats a" is a property of the position, the chain of
+        //     deferrals from j the run of such positions from j on (full-budget table only)
+        if (s.cfg.mode == MODE_LAZY && !s.cfg.use_quarter) {
+            const uint32_t L0 = m_len((uint32_t)M(j));
+            const bool ok = j + 2 < n && L0 >= MIN_MATCH && !match_too_far(L0, m_dist((uint32_t)M(j)));
+            uint64_t a = j;
+            if (ok)
+                while (m_len((uint32_t)M(a)) < s.cfg.lazy_lt && a + 3 < n && m_len((uint32_t)M(a + 1)) > m_len((uint32_t)M(a))) a++;
+            const uint32_t want = ok ? (uint32_t)(a - j) + m_len((uint32_t)M(a)) : 1u;
+            if (want != st.adv || (ok && (uint32_t)(a - j) != st.nlit)) s.hier_mismatch = true;
+        }
+    }
     uint64_t K = (n + S - 1) / S;
     if (K == 0) return;
     // level 0: X[k][e] = first path position >= seg_end starting from seg_start + e

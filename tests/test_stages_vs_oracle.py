@@ -23,7 +23,7 @@ def agree(data, c, l, m, seg=1024, fan=4):
     rb = ob.trace_blocks()
     rc, out, flags, bl = hs.encode(data, c, l, m, seg, fan)
     assert rc == 0
-    assert not (flags & 4), "hierarchical path search disagrees with the direct walk"
+    assert not (flags & 4), "hierarchical path search, a step read off its filed entry or the loop-free lazy step disagrees with the direct walk"
     assert bl == rb
     assert out == ref
     return flags
