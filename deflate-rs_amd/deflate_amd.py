@@ -240,7 +240,7 @@ class Context:
     def _err(self, rc):
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
 
-    CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS, CFG_HOST_STREAMING, CFG_MULTI_STITCH = 1, 2, 3, 4, 5
+    CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS, CFG_HOST_STREAMING, CFG_MULTI_STITCH, CFG_STEPS_IN_EMIT = 1, 2, 3, 4, 5, 6
 
     def config(self, key, value):
         """mi355_deflate_ctx_config: range size / long-input threshold / where the sort takes its ranks from"""

@@ -129,12 +129,18 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          mi355_deflate_encode_multi_device reach rank 0's device: 0 (default) = peer copies
  *                          (hipMemcpyPeerAsync: xGMI between the GPUs of a node), 1 = RCCL -- one ncclSend per rank, the
  *                          matching ncclRecv posted by rank 0's thread straight into the caller's buffer; librccl.so is
- *                          looked up when the first such call is made (MI355_E_UNSUPPORTED if it is not there). */
+ *                          looked up when the first such call is made (MI355_E_UNSUPPORTED if it is not there).
+ *   MI355_CFG_STEPS_IN_EMIT  where the parser's restart steps (lz77.rs:305-547 seen from a position) are worked out: 1 (default) =
+ *                          by the kernel that writes the tokens, from the match table, where that is possible (the lazy and
+ *                          greedy levels without a quarter-budget table, input without flush points); 0 = always by a kernel
+ *                          of their own that leaves them in device memory (what the exact path search, `Best` and flushed
+ *                          streams use anyway).  Same bytes either way: a testing and measuring aid. */
 #define MI355_CFG_RANGE_BYTES 1
 #define MI355_CFG_LONG_FROM 2
 #define MI355_CFG_SORT_RANKS 3
 #define MI355_CFG_HOST_STREAMING 4
 #define MI355_CFG_MULTI_STITCH 5
+#define MI355_CFG_STEPS_IN_EMIT 6
 int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers

@@ -1822,3 +1822,29 @@ def test_c_example_program(tmp_path):
             else:
                 want = ob.encode(data, level=lvl[1], wrapper=1 if flag == "-zlib" else 0)
             assert got == want, (flag, lvl[0], extra)
+
+
+# The restart steps (lz77.rs:305-547 seen from a position) worked out by the kernel that writes the tokens, from the match table --
+# the lazy step as a run of per-position bits, a step read off its filed entry -- or by k_adv into device memory
+# (MI355_CFG_STEPS_IN_EMIT 1 / 0): the oracle's bytes either way, on inputs with long deferral chains, ends inside a chain,
+# segments that end in the middle of a match, and the levels that take the one way or the other.
+def test_restart_steps_in_the_token_kernel_or_from_k_adv(da):
+    ctx = da.Context(0)
+    try:
+        rnd = __import__("random").Random(77)
+        # ascending matches in a row: position p+1 has a longer match than p, many times over (chains of deferrals)
+        base = bytes(rnd.randrange(256) for _ in range(600))
+        climb = b"".join(base[i:i + 40 + k] + bytes([k & 0xFF, (k * 7) & 0xFF]) for k, i in enumerate(range(0, 400, 3)))
+        inputs = [("text", datagen.text_like(3_000_001, 31)), ("mixed", datagen.mixed(2_000_000, 32)),
+                  ("chains", (base + climb) * 40), ("short", datagen.text_like(1151, 33)), ("two", b"ab"),
+                  ("tail", datagen.text_like(70_000, 34) + b"xyzxyzxyzxy")]
+        for name, data in inputs:
+            for lv in ("default", "fast", "best"):
+                for where in (1, 0):
+                    ctx.config(da.Context.CFG_STEPS_IN_EMIT, where)
+                    try:
+                        agree(da, ctx, data, *LV[lv])
+                    except AssertionError as e:
+                        raise AssertionError("%s %s MI355_CFG_STEPS_IN_EMIT=%d: %s" % (name, lv, where, e))
+    finally:
+        ctx.close()
