@@ -2775,15 +2775,66 @@ __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint64_t bits, uint32_t nbits);
 
-__global__ __launch_bounds__(64) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
-                                             const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
-                                             BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
-                                             const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc) {
-    const uint32_t lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
+                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
+                                               BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
+                                               const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc) {
+    __shared__ uint32_t s_red[16], s_flag[3];
+    const uint32_t lane = threadIdx.x & 63;
     if (spec_failed(sc)) return;
     // (a piece: the blocks from sc->nbcum[pc.p] on, behind the bits planned so far; `fin` = the block that ends the stream)
     const uint32_t nb = sc->nb, fin = pc.last ? nb : 0xFFFFFFFFu;
     uint64_t bitpos = bit_base + sc->total_bits;
+    // A thread per block where the piece has at most 1024 of them (110 MB of text) and none depends on the bit phase it
+    // starts at -- no Stored block, no sync marker: type and length the same for all eight phases --: the bit offsets are a
+    // prefix sum over the workgroup.  (One wave, 64 blocks a round with the eight phases of each worked out by its lane, took
+    // 22 us for the 937 blocks of the 100 MB text: fifteen rounds of arithmetic, not of memory.)  Anything else is the
+    // one wave's walk below.
+    {
+        const uint32_t first = sc->nbcum[pc.p], nbp = nb > first ? nb - first : 0u;
+        const uint32_t b = first + threadIdx.x;
+        const bool have = threadIdx.x < nbp;
+        bool plain = nbp <= 1024;
+        BlockPlan p0;
+        p0.btype = BT_FIXED;
+        p0.bfinal = 0;
+        p0.bit_start = 0;
+        p0.bit_len = 0;
+        if (plain && have) {
+            const uint64_t dyn_bits = hdr[b].dyn_bits, dyn_est = hdr[b].dyn_est, static_est = hdr[b].static_est,
+                           fixed_bits = hdr[b].fixed_bits, in_bytes = (uint64_t)bstart[b + 1] - bstart[b];
+            plain = blk_sync[b] == 0;
+            plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == fin, 0, &p0);
+            plain = plain && p0.btype != BT_STORED;
+#pragma unroll
+            for (uint32_t ph = 1; ph < 8; ph++) {
+                BlockPlan q;
+                plan_block(dyn_bits, dyn_est, static_est, fixed_bits, in_bytes, b + 1 == fin, ph, &q);
+                plain = plain && q.btype == p0.btype && q.bit_len == p0.bit_len;
+            }
+        }
+        if (threadIdx.x < 3) s_flag[threadIdx.x] = 0;
+        __syncthreads();
+        if (!plain) s_flag[0] = 1;
+        if (plain && have) atomicAdd(&s_flag[p0.btype == BT_FIXED ? 1 : 2], 1u);
+        __syncthreads();
+        if (s_flag[0] == 0) {
+            uint32_t total = 0;
+            const uint32_t mylen = have ? (uint32_t)p0.bit_len : 0u;  // < 2^21 for a block that is not stored
+            const uint32_t before = block_excl_scan_1024(mylen, s_red, &total);
+            if (have) {
+                p0.bit_start = bitpos + before;
+                plan[b] = p0;
+            }
+            if (threadIdx.x == 0) {
+                sc->total_bits = bitpos + total - bit_base;
+                sc->n_fixed += s_flag[1];
+                sc->n_dynamic += s_flag[2];
+            }
+            return;
+        }
+        if (threadIdx.x >= 64) return;  // (whole waves; no barrier below)
+    }
     uint32_t n_st = 0, n_fx = 0, n_dy = 0, hits = 0, panic = 0;
     for (uint32_t b0 = sc->nbcum[pc.p]; b0 < nb; b0 += 64) {
         uint32_t b = b0 + lane;
