@@ -3005,11 +3005,11 @@ __device__ __forceinline__ void put_bits_lds(uint32_t* buf, uint32_t bitpos, uin
     if (hi) atomicOr(buf + w + 2, hi);
 }
 
-struct PackLds {
+struct alignas(4) PackLds {
     uint16_t llc[288];
     uint16_t dc[32];
     uint16_t clc[20];
-    uint8_t lll[288];
+    uint8_t lll[288];  // (the three length arrays start at multiples of four bytes: k_pack reads them four at a time)
     uint8_t dl[32];
     uint8_t cll[20];   // code-length code lengths of a dynamic block
     uint32_t cnt[48];   // canonical codes: symbols per code length, then first code per length; [table][16]
@@ -3118,8 +3118,21 @@ __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, ui
         const uint32_t k = i < 288 ? i : (i < 320 ? i - 288 : i - 320);
         const uint32_t l = len[k];
         uint32_t r = 0;
-        if (l)
-            for (uint32_t j = 0; j < k; j++) r += len[j] == l ? 1u : 0u;
+        if (l) {
+            // (the symbols before k with its length, four lengths a read: byte by byte this loop was up to 287 dependent LDS
+            // reads a thread, a third of the kernel's table building; the three arrays are 4-byte aligned)
+            const uint32_t* lw = reinterpret_cast<const uint32_t*>(len);
+            const uint32_t pat = l * 0x01010101u, whole = k >> 2, rem = k & 3u;
+#pragma unroll 4
+            for (uint32_t w = 0; w < whole; w++) {
+                const uint32_t z = lw[w] ^ pat;
+                r += (uint32_t)__builtin_popcount(~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z) & 0x80808080u);  // its zero bytes
+            }
+            if (rem) {
+                const uint32_t z = lw[whole] ^ pat;
+                r += (uint32_t)__builtin_popcount(~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z) & 0x80808080u & ((1u << (8 * rem)) - 1u));
+            }
+        }
         codes[k] = l ? (uint16_t)reverse_bits16((first[l] + r) & 0xffff, l) : (uint16_t)0;
     }
     __syncthreads();
