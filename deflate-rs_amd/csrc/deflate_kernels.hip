@@ -631,9 +631,9 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
 #ifndef MI355_SORT_ROUNDS
 #define MI355_SORT_ROUNDS 1  // (measured on the 100 MB text: k_sort 0.440 ms without, 0.427 with one digit from 4 / 8 lanes on, 0.43 from 16;
 #endif                       //  two / three digits that way 0.47 / 0.50 -- every round is a dependent read and write of the counter)
-#ifndef MI355_SORT_ROUNDS_LOW
-#define MI355_SORT_ROUNDS_LOW 0  // ... in the pass over the LOW digit, whose batches are keys in position order and meet on no counter
-#endif                           // in particular: none there (0.427 -> 0.413 ms under the profiler; one in both passes before)
+// (... in the pass over the high digit, and in the pass over the LOW digit only for an epoch with runs of one byte -- zero fill: all
+// of a batch on one counter, 0.98 against 1.68 ms for 256 MiB -- : its batches are keys in position order and meet on no counter in
+// particular otherwise, where the look for a first digit only cost: 0.427 -> 0.413 ms under the profiler on the text)
 #ifndef MI355_SORT_SB
 #define MI355_SORT_SB 4  // batches whose digits are fetched together in the count phase of sort_pass_rtn
 #endif
@@ -646,7 +646,7 @@ __device__ __forceinline__ void sort_pass(uint32_t J, uint32_t* cnt /*16 * 256*/
 // counter would be served one after the other.
 template <int NB, bool LOW, class Dig, class Pay, class Put>
 __device__ __forceinline__ void sort_pass_rtn(uint32_t J, uint32_t* cnt /*16 * 256*/, uint32_t* red, Dig dig, Pay pay, Put put,
-                                              unsigned long long& ks_t, int stat0) {
+                                              unsigned long long& ks_t, int stat0, bool hot_low) {
     constexpr uint32_t ND = 1u << NB;
     constexpr int NBAT = SORT_CHUNK / 64;  // batches per wave
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -672,7 +672,8 @@ __device__ __forceinline__ void sort_pass_rtn(uint32_t J, uint32_t* cnt /*16 * 2
         uint64_t left = vm;
         bool mine_done = !valid;
 #pragma unroll
-        for (int round = 0; round < (LOW ? MI355_SORT_ROUNDS_LOW : MI355_SORT_ROUNDS); round++) {
+        for (int round = 0; round < MI355_SORT_ROUNDS; round++) {
+            if (LOW && !hot_low) break;
             if (left == 0) break;
             const uint32_t first = (uint32_t)__builtin_ctzll(left);
             const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)first);
@@ -912,12 +913,13 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     uint16_t* buf16 = reinterpret_cast<uint16_t*>(sBuf);
     if (MODE == 1) {
         constexpr int P1 = MI355_SORT_P1;  // bits of the first digit (the per-wave counter tables hold 256: 7 or 8)
+        const bool runs_here = __builtin_amdgcn_readfirstlane((int)s_runs) != 0;  // (final since the barrier behind the hashes)
         sort_pass_rtn<P1, true>(
             J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & ((1u << P1) - 1u); }, [&](uint32_t i) { return i; },
-            [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2);
+            [&](uint32_t at, uint32_t v) { buf16[at] = (uint16_t)v; }, ks_t, 2, runs_here);
         sort_pass_rtn<15 - P1, false>(
             J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[buf16[i]] >> P1; }, [&](uint32_t i) { return (uint32_t)buf16[i]; },
-            [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5);
+            [&](uint32_t at, uint32_t v) { sH[at] = (uint16_t)v; }, ks_t, 5, false);
     } else {
     sort_pass<8>(
         J, sCnt, sRed, [&](uint32_t i) { return (uint32_t)sH[i] & 255u; }, [&](uint32_t i) { return i; },
