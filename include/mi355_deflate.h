@@ -125,6 +125,8 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          0 = one copy-out after the last kernel; 2 = pieces with their stages behind each other
  *                          (a measuring aid).  Same bytes every way; data the piecewise form does not take (a hash re-warm
  *                          in the first window, long periodic data) is encoded the other way without the caller noticing.
+ *                          (Measuring aids, read once per process: the environment variables MI355_HOST_PLAN="1,2,3,3" -- rounds of
+ *                          256 windows per piece -- and MI355_HOST_FIRST=<windows of the first piece, 0 = a whole round>.)
  *   MI355_CFG_MULTI_STITCH  (of rank 0's context of a mi355_multi handle: mi355_multi_ctx(m, 0)) how the packed ranges of
  *                          mi355_deflate_encode_multi_device reach rank 0's device: 0 (default) = peer copies
  *                          (hipMemcpyPeerAsync: xGMI between the GPUs of a node), 1 = RCCL -- one ncclSend per rank, the
