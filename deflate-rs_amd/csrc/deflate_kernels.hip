@@ -2232,7 +2232,11 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __r
     uint32_t lane = threadIdx.x & 63;
     uint32_t c = cnt[k], b = base[k];
     const uint32_t* src = tokbuf + k * SEG;
-    for (uint32_t i = lane; i < c; i += 64) dtok[b + i] = src[i];
+    // (sixteen bytes a lane -- the slot is 4 KiB aligned, the dense array takes them at any dword --: with four bytes a lane the copy
+    // ran at 4.4 TB/s and looked bound by memory; 53 -> 38 us)
+    const uint32_t c4 = c & ~3u;
+    for (uint32_t i = 4 * lane; i < c4; i += 256) *reinterpret_cast<uint4*>(dtok + b + i) = *reinterpret_cast<const uint4*>(src + i);
+    if (lane < (c & 3u)) dtok[b + c4 + lane] = src[c4 + lane];
 }
 
 // start position of token t (t < T); the whole wave calls it.  The segment that holds the token -- the last k with
