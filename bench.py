@@ -10,8 +10,15 @@ fill through the RLE path (config 2); "random" = 64 MiB noise (stored blocks); "
 Silesia-like mix at Compression::Best (config 4); "webtext" = config 5: every rank owns 1 GiB of ONE
 N GiB web-text input (generated per 1 MiB segment, so a rank makes exactly its own part).
 
+N > 1 (`python bench.py --gpus N`, with or without torch.distributed.run around it: without, bench.py launches itself under it):
+one process per GPU over RCCL, the workload defaults to config 5 -- every rank owns 1 GiB of ONE N GiB web-text input, 8 GiB at
+N = 8 -- and the line says what RCCL saw (rccl_ranks), how the stream was stitched, rank 0's phases, and whether the stitched
+stream is the oracle's (committed digests, tests/golden/config5_digest*.json).  --virtual: the N ranks share the GPUs the box has
+(gloo carries the exchanges) -- the dry run of a one-GPU box.  --single-process: the same sharding inside ONE call of the C ABI.
+
 Besides the contract's fields the line carries: value_host_api (the drop-in call on pinned host buffers,
-H2D and D2H inside the timed region), roofline.input_load (achieved HBM GB/s of the kernel that reads
+H2D and D2H inside the timed region), value_host_api_pageable (the same call on the memory a drop-in caller has: a plain
+bytearray in and out -- the context's host threads carry it; beside it the runtime's own copies, MI355_CFG_HOST_BOUNCE = 0), roofline.input_load (achieved HBM GB/s of the kernel that reads
 the input coalesced), roofline.lds_bank_conflict_rate of the match compare and roofline.valu_issue (wave
 instructions per input byte and the share of the SIMDs' cycles they take: what the dominant kernel is bound
 by; both from the committed PMC file),
@@ -55,6 +62,14 @@ def make_input(workload, size, rank):
         d = datagen.silesia_like(0x53494C45 ^ rank)
         return d if size >= len(d) else d[:size]
     if workload == "webtext":  # BASELINE config 5: this rank's part of the one big input
+        seg = datagen.WEB_SEGMENT
+        if size >= (64 << 20) and size % seg == 0 and "torch" not in sys.modules:
+            # (a GiB a rank: generated a MiB segment at a time on a few cores -- before torch and HIP are loaded, so forking is safe)
+            import multiprocessing as mp
+            first = rank * size // seg
+            nproc = max(1, min(16, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+            with mp.get_context("fork").Pool(nproc) as pool:
+                return b"".join(pool.map(datagen.webtext_segment_bytes, range(first, first + size // seg), chunksize=8))
         return datagen.webtext(size, start=rank * size)
     raise SystemExit("unknown workload " + workload)
 
@@ -109,36 +124,38 @@ def cpu_baselines(data, olvl, level_name):
             "zlib6_anchor": {"value": round(z6, 2), "unit": "MB/s", "cores": 1, "note": "system zlib -6, not the reference"}}
 
 
-def single_process(args, da):
+def single_process(args):
     """N GPUs of the node, ONE process: the library shards the input itself (row h of SURVEY section 8).  Weak scaling like
     the multi-process form: every device owns `size` bytes of one N x size input, resident in its HBM with its history and
     look-ahead; the stream lands in device 0's memory.  value = N x size bytes / step."""
-    import torch
     N = args.gpus
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    ndev = torch.cuda.device_count()
-    devs = [0] * N if args.virtual else list(range(N))
-    if not args.virtual and ndev < N:
-        raise SystemExit("--gpus %d but %d devices visible (use --virtual for a one-GPU dry run)" % (N, ndev))
     size = args.size or {"enwik8": 100_000_000, "webtext": 1 << 30}.get(args.workload, 100_000_000)
     size = (size + 32767) // 32768 * 32768
     total = N * size
+    part = {r: make_input(args.workload, size, r) for r in range(N)}  # (before torch and HIP are loaded: made on a pool of processes)
+    import torch
+    import deflate_amd as da
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if not args.virtual and ndev < N:
+        raise SystemExit("--gpus %d but %d devices visible (use --virtual for a dry run on the devices there are)" % (N, ndev))
+    devs = [r % ndev for r in range(N)]
     lvl = args.level or "default"
     options = {"default": da.CompressionOptions.default, "best": da.CompressionOptions.high,
                "fast": da.CompressionOptions.fast}[lvl]()
     level_name = {"default": "Compression::Default", "best": "Compression::Best", "fast": "Compression::Fast"}[lvl]
     m = da.MultiGpu(devs)
+    stitch = args.stitch
+    if stitch == "rccl":
+        m.config(da.Context.CFG_MULTI_STITCH, 1)
     lay = [m.layout(total, r) for r in range(N)]
     assert lay[0]["n_ranks"] == N
-    # every rank makes its own bytes [g_lo, g_hi): its part of the one input, the last 32 KiB of the part before, the first
+    # every rank holds its own bytes [g_lo, g_hi): its part of the one input, the last 32 KiB of the part before, the first
     # 128 KiB of the part behind
     bufs = []
-    part = {}
 
     def piece(r):
-        if r not in part:
-            part[r] = make_input(args.workload, size, r)
         return part[r]
     for r in range(N):
         L = lay[r]
@@ -157,6 +174,14 @@ def single_process(args, da):
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda:%d" % devs[0])
     ptrs = [b.data_ptr() for b in bufs]
     n = 0
+    try:
+        n = m.encode_device(ptrs, total, d_out.data_ptr(), cap, options)
+    except da.DeflateError as e:
+        if stitch != "rccl":
+            raise
+        sys.stderr.write("bench.py: the RCCL stitch is not available here (%s): peer copies\n" % e)
+        stitch = "peer"
+        m.config(da.Context.CFG_MULTI_STITCH, 0)
     for _ in range(args.warmup):
         n = m.encode_device(ptrs, total, d_out.data_ptr(), cap, options)
     for d in set(devs):
@@ -180,25 +205,117 @@ def single_process(args, da):
            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
            "data": "real" if "real" in INPUT_NOTE.get(args.workload, "") else "synthetic",
            "config": {"workload": "%s%s: %d bytes per GPU, %s, one %d-byte input sharded over %d %s in ONE process "
-                                  "(mi355_deflate_encode_multi_device), stream-exact (P1), stitch by peer copies" % (
+                                  "(mi355_deflate_encode_multi_device), stream-exact (P1), stitch by %s" % (
                                       args.workload, " = " + INPUT_NOTE[args.workload] if args.workload in INPUT_NOTE else "", size,
-                                      level_name, total, N, "ranks that SHARE device 0 (dry run)" if args.virtual else "GPUs"),
+                                      level_name, total, N, "ranks that SHARE %d device(s) (dry run)" % ndev if ndev < N else "GPUs",
+                                      "ncclSend / ncclRecv" if stitch == "rccl" else "peer copies"),
                       "bytes_per_gpu": size, "level": level_name, "parallelism": "shard%d" % N},
            "out_bytes": n, "ratio": round(n / total, 5),
            "roofline": {"bound": "hbm", "kernel": "k_match3", "achieved": round(algo / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": algo},
            "multi_phases_ms_rank0": tr}
+    si = m.stitch_info()
+    res["stitch"] = si["stitch"]
+    res["rccl_ranks"] = si["rccl_ranks"]  # (what the communicator of rank 0's device reports: one RCCL rank per distinct device)
+    res["devices"] = ndev
+
+    def parts():
+        for i in range(0, n, 256 << 20):
+            yield bytes(d_out[i:min(n, i + (256 << 20))].cpu().numpy())
+    res.update(stream_check(args.workload, total, size, N, lvl, parts, n))
+    m.close()  # (RCCL says goodbye on stdout when its communicators go: the line comes last)
+    sys.stdout.flush()
     print(json.dumps(res))
-    m.close()
 
 
-def main():
+def device_count():
+    """HIP devices of the box, without loading torch (mi355_device_count of the C ABI; 0: no GPU or no HIP runtime)"""
+    import deflate_amd as da
+    try:
+        return int(da.load().mi355_device_count())
+    except Exception:
+        return 0
+
+
+def launch_plan(args, argv, n_dev):
+    """`python bench.py --gpus N` without torch.distributed.run around it: the command that starts the N ranks -- what the
+    driver runs for N > 1 -- and its environment.  A box with fewer GPUs than ranks runs it only as a dry run (--virtual):
+    the ranks share the devices and the exchanges travel over gloo."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), "MASTER_ADDR": "127.0.0.1"}
+    note = "one rank per GPU, RCCL"
+    if n_dev < args.gpus:
+        if not args.virtual:
+            return {"error": "--gpus %d but %d devices visible; --virtual runs the %d ranks on the devices there are (a dry run: "
+                             "gloo carries the exchanges)" % (args.gpus, n_dev, args.gpus)}
+        env["MI355_BENCH_BACKEND"] = "gloo"
+        env["MI355_BENCH_VIRTUAL"] = "1"
+        note = "dry run: %d ranks on %d device(s), exchanges over gloo" % (args.gpus, n_dev)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a not in ("--dry-run", "--virtual")]
+    # (--virtual travels in the environment: torch.distributed.run's own parser trips over it -- "ambiguous option")
+    return {"cmd": cmd, "env": env, "note": note}
+
+
+def self_launch(args, argv):
+    import subprocess
+    plan = launch_plan(args, argv, device_count())
+    if args.dry_run:
+        print(json.dumps({"launch": plan}))
+        return 0
+    if "error" in plan:
+        raise SystemExit(plan["error"])
+    env = dict(os.environ)
+    env.update(plan["env"])
+    sys.stderr.write("bench.py: %s\n" % plan["note"])
+    return subprocess.call(plan["cmd"], env=env)
+
+
+def committed_digest(workload, total, lvl):
+    """length and SHA-256 of the ORACLE's stream of this very input, where one is committed (tests/golden/)"""
+    if workload != "webtext" or lvl != "default":
+        return None
+    for name in ("config5_digest.json", "config5_digest_%d.json" % total):
+        p = os.path.join(ROOT, "tests", "golden", name)
+        if os.path.isfile(p):
+            g = json.load(open(p))["digests"]["raw"]
+            if g["in_len"] == total:
+                return {"out_len": g["out_len"], "out_sha256": g["out_sha256"], "file": "tests/golden/" + name}
+    return None
+
+
+def stream_check(workload, total, per_rank, world, lvl, out_bytes_fn, out_len):
+    """Is the stitched stream the oracle's?  By a committed digest where there is one (config 5 and its smaller totals), by the
+    oracle run on the whole input here when that takes seconds, else unknown (None)."""
+    import hashlib
+    gold = committed_digest(workload, total, lvl)
+    if gold is not None:
+        h = hashlib.sha256()
+        for part in out_bytes_fn():
+            h.update(part)
+        return {"bit_exact_vs_oracle": bool(out_len == gold["out_len"] and h.hexdigest() == gold["out_sha256"]),
+                "oracle_digest": gold["file"], "ref_out_bytes": gold["out_len"]}
+    if total <= 512_000_000 and lvl in ("default", "best", "fast"):
+        import oracle_binding as ob
+        whole = b"".join(make_input(workload, per_rank, r) for r in range(world))
+        ref = ob.encode(whole, level={"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST}[lvl])
+        got = b"".join(out_bytes_fn())
+        return {"bit_exact_vs_oracle": bool(got == ref), "oracle_digest": "the oracle run on the %d bytes here" % total,
+                "ref_out_bytes": len(ref)}
+    return {"bit_exact_vs_oracle": None, "oracle_digest": None}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="enwik8", choices=["enwik8", "zeros", "random", "silesia", "webtext"])
+    ap.add_argument("--workload", default="", choices=["", "enwik8", "zeros", "random", "silesia", "webtext"],
+                    help="default: enwik8 (BASELINE config 3) on one GPU, webtext (config 5: 1 GiB per GPU of one N GiB input) on several")
     ap.add_argument("--size", type=int, default=0, help="bytes per GPU (0 = the config's size)")
     ap.add_argument("--level", default="", choices=["", "default", "best", "fast", "rle", "huffman_only"],
                     help="override the level of the workload (default: Default, rle() for zeros)")
@@ -208,9 +325,39 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torch.distributed: one process drives all --gpus devices through "
                          "mi355_deflate_encode_multi_device (a thread per device inside the library)")
-    ap.add_argument("--virtual", action="store_true", help="with --single-process: the N ranks share device 0 (one-GPU dry run)")
+    ap.add_argument("--virtual", action="store_true",
+                    help="N > 1 on a box with fewer GPUs: the ranks share the devices there are (rank r on device r %% devices; "
+                         "one process per rank with gloo for the exchanges, or with --single-process inside one call)")
+    ap.add_argument("--stitch", default="rccl", choices=["rccl", "peer"],
+                    help="--single-process: how the packed ranges reach rank 0's device (MI355_CFG_MULTI_STITCH)")
+    ap.add_argument("--dry-run", action="store_true", help="N > 1 without torch.distributed.run: print the launch as JSON and stop")
     ap.add_argument("--pmc-file", default="", help="PMC summary to take roofline.traffic from (default: newest profiles/r*_pmc_summary.json)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    args.virtual = args.virtual or os.environ.get("MI355_BENCH_VIRTUAL") == "1"
+    if not args.workload:
+        args.workload = "enwik8" if args.gpus == 1 else "webtext"
+    launched = "WORLD_SIZE" in os.environ  # (torch.distributed.run sets it, for one process too)
+    if args.gpus > 1 and not launched and not args.single_process:
+        return self_launch(args, sys.argv[1:] if argv is None else list(argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not args.single_process:
+        raise SystemExit("--gpus %d but torch.distributed.run started %d processes" % (args.gpus, world))
+    sizes = {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024, "silesia": 212_100_000, "webtext": 1 << 30}
+    size = args.size or sizes[args.workload]
+    if world > 1 or args.single_process:
+        size = (size + 32767) // 32768 * 32768  # rank ranges of the one big input are 32 KiB aligned
+    data = None
+    if not (args.single_process and args.gpus > 1):
+        data = make_input(args.workload, size, rank)  # (before torch and HIP are loaded: a large one is made on a pool of processes)
+        if len(data) != size:
+            raise SystemExit("workload %s gives %d bytes, not %d" % (args.workload, len(data), size))
+
+    if args.single_process and args.gpus > 1:
+        return single_process(args)
 
     import torch
     import torch.distributed as dist
@@ -218,19 +365,16 @@ def main():
     import deflate_amd as da
     import shard
 
-    if args.single_process and args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        return single_process(args, da)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # MI355_BENCH_BACKEND=gloo lets several ranks share one GPU (dry run of the N > 1 path on a 1-GPU box):
     # exchanged tensors then travel through host memory; the default is RCCL over xGMI.
     backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    if world > torch.cuda.device_count() and backend == "nccl":
+        if not args.virtual:
+            raise SystemExit("--gpus %d but %d devices visible: RCCL takes one rank per device (--virtual: the ranks share the "
+                             "devices and gloo carries the exchanges -- a dry run)" % (world, torch.cuda.device_count()))
+        backend = "gloo"
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     cdev = "cuda" if backend == "nccl" else "cpu"
@@ -239,11 +383,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    size = args.size or {"enwik8": 100_000_000, "zeros": 256 * 1024 * 1024, "random": 64 * 1024 * 1024,
-                         "silesia": 212_100_000, "webtext": 1 << 30}[args.workload]
     shard_mode = os.environ.get("MI355_SHARD_MODE", "p1") if world > 1 else "single"
-    if world > 1:
-        size = (size + 32767) // 32768 * 32768  # rank ranges of the one big input are 32 KiB aligned
     lvl = args.level or {"zeros": "rle", "silesia": "best"}.get(args.workload, "default")
     options = {"default": da.CompressionOptions.default, "best": da.CompressionOptions.high,
                "fast": da.CompressionOptions.fast, "rle": da.CompressionOptions.rle,
@@ -251,10 +391,9 @@ def main():
     level_name = {"default": "Compression::Default", "best": "Compression::Best", "fast": "Compression::Fast",
                   "rle": "rle()", "huffman_only": "huffman_only()"}[lvl]
 
-    data = make_input(args.workload, size, rank)
-    if len(data) != size:
-        raise SystemExit("workload %s gives %d bytes, not %d" % (args.workload, len(data), size))
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    if world > 1:
+        data = None  # (a GiB a rank: the device holds it from here on)
     cap = da.bound(size) + 8
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     ctx = da.Context(dev_index)
@@ -306,14 +445,16 @@ def main():
         assert d_ext.numel() - 64 == layout["g_hi"] - layout["g_lo"]
 
     out_len = [0]
+    last_img = [None]
     match_ms = []
     stage_ms = {}
     gpu_ms = []
 
     def step(record):
         if shard_mode == "p1":
-            _, n = shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev)
+            img, n = shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev)
             out_len[0] = n if rank == 0 else 0
+            last_img[0] = img  # (rank 0: a view of the stitched stream, valid until the next step)
             if record:
                 info = ctx.info()
                 match_ms.append(info["match_ms"] / max(1, info["match_launches"]))
@@ -343,9 +484,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     p1_trace = None
+    rccl_ranks = 0
     if shard_mode == "p1":  # one more step, untimed, with a device synchronisation after every phase
-        shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev, trace=True)
+        img, _ = shard.encode_p1_dist(da, ctx, d_ext, layout, total, rank, world, options, comm_device=cdev, trace=True)
+        last_img[0] = img
         p1_trace = dict(shard.LAST_TRACE)
+    if world > 1 and backend == "nccl":
+        # what RCCL itself saw: a sum of ones over the communicator the steps used, on the devices
+        ones = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -434,6 +582,17 @@ def main():
         }
         if p1_trace is not None:
             res["p1_phases_ms_rank0"] = p1_trace  # (one untimed step, synchronised per phase)
+        if world > 1:
+            res["rccl_ranks"] = rccl_ranks  # (0: the exchanges did not travel over RCCL -- the gloo dry run)
+            res["stitch"] = "rccl" if backend == "nccl" else backend
+            res["devices"] = torch.cuda.device_count()
+            if shard_mode == "p1" and last_img[0] is not None:
+                img = last_img[0]
+
+                def parts():
+                    for i in range(0, total_out, 256 << 20):
+                        yield bytes(img[i:min(total_out, i + (256 << 20))].cpu().numpy())
+                res.update(stream_check(args.workload, total, size, world, lvl, parts, total_out))
         if world == 1 and not args.no_host_api:
             # the drop-in call itself, deflate_bytes(&[u8]) -> Vec<u8> (src/lib.rs:163): pinned host buffers,
             # first H2D byte to last D2H byte inside the timed region
@@ -457,6 +616,37 @@ def main():
                                              "kernels and the copy engine's D2H overlap)",
                                      "same_bytes": bool(hn == out_len[0] and torch.equal(
                                          h_out[:hn], d_out[:hn].cpu()))}
+        if world == 1 and not args.no_host_api:
+            # ... and on the memory a drop-in caller has (src/lib.rs:137-147: &[u8] in, Vec<u8> out): plain pageable buffers.
+            # The context's host threads carry them through page-locked slots (MI355_CFG_HOST_BOUNCE, deflate_bounce.inc);
+            # beside it the same call with the threads off -- the runtime's own copies, one after the other
+            import ctypes
+            import numpy as np
+            p_in = np.frombuffer(data, dtype=np.uint8).copy()
+            p_out = np.zeros(cap + 64, dtype=np.uint8)  # (touched: a fresh Vec's page faults are the caller's in any implementation)
+            reps = max(2, args.steps)
+
+            def pageable(bounce):
+                ctx.config(da.Context.CFG_HOST_BOUNCE, bounce)
+                hn = ctx.encode_host_ptr(p_in.ctypes.data, size, p_out.ctypes.data, cap + 64, options)
+                calls = []
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    tc = time.perf_counter()
+                    hn = ctx.encode_host_ptr(p_in.ctypes.data, size, p_out.ctypes.data, cap + 64, options)
+                    calls.append((time.perf_counter() - tc) * 1e3)
+                dt = time.perf_counter() - t1
+                return {"value": round(size * reps / dt / 1e6, 2), "unit": "MB/s", "ms_per_call": round(dt * 1e3 / reps, 3),
+                        "call_ms": {"min": round(min(calls), 3), "median": round(sorted(calls)[len(calls) // 2], 3),
+                                    "max": round(max(calls), 3), "n": len(calls)},
+                        "host_path": ctx.info()["host_path"],
+                        "same_bytes": bool(hn == out_len[0] and np.array_equal(p_out[:hn], d_out[:hn].cpu().numpy()))}
+            slow = pageable(0)
+            fast = pageable(1)
+            fast["what"] = ("mi355_deflate_encode on PAGEABLE host buffers (numpy arrays: what a &[u8] / Vec<u8> caller hands over), "
+                            "first byte in to last byte out; host_path bits: 1 pieces, 2 input by the context's host threads, 4 output by them")
+            fast["runtime_copies"] = slow  # (MI355_CFG_HOST_BOUNCE = 0: what such a caller got before)
+            res["value_host_api_pageable"] = fast
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
             olvl = {"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST, "rle": ob.RLE,
@@ -469,10 +659,13 @@ def main():
             got = bytes(d_out[: out_len[0]].cpu().numpy())
             res["ref_out_bytes"] = len(ref)
             res["bit_exact_vs_oracle"] = bool(got == ref)
-        print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res))  # (the line comes last on stdout, behind anything the communicators print when they go)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

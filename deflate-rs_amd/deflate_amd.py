@@ -32,7 +32,7 @@ class Info(C.Structure):
                 ("n_dynamic", C.c_uint32), ("q1_rewarm", C.c_uint32), ("q13_hits", C.c_uint32),
                 ("passes", C.c_uint32), ("spec_fallback", C.c_uint32), ("stage_ms", C.c_float * 6),
                 ("total_ms", C.c_float), ("match_launches", C.c_uint32), ("match_ms", C.c_float),
-                ("spec_repaired", C.c_uint32), ("reserved", C.c_uint32)]
+                ("spec_repaired", C.c_uint32), ("host_path", C.c_uint32)]
 
 
 class BlockInfo(C.Structure):
@@ -185,6 +185,7 @@ def load():
     L.mi355_deflate_encode_multi_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(Opts), C.c_char_p,
                                                     C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mi355_multi_last_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+    L.mi355_multi_stitch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi355_deflate_ctx_config.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     L.mi355_deflate_stream_held_bytes.argtypes = [C.c_void_p]
     L.mi355_deflate_stream_held_bytes.restype = C.c_uint64
@@ -210,6 +211,7 @@ EXPORTED = [
     "mi355_deflate_ctx_config", "mi355_deflate_stream_held_bytes",
     "mi355_device_count", "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_devices", "mi355_multi_ctx", "mi355_multi_last_error",
     "mi355_multi_layout", "mi355_deflate_encode_multi", "mi355_deflate_encode_multi_device", "mi355_multi_last_trace",
+    "mi355_multi_stitch_info",
 ]
 
 
@@ -241,6 +243,8 @@ class Context:
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
 
     CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS, CFG_HOST_STREAMING, CFG_MULTI_STITCH, CFG_STEPS_IN_EMIT = 1, 2, 3, 4, 5, 6
+    CFG_HOST_BOUNCE, CFG_HOST_THREADS = 7, 8
+    HOST_PATH_PIECES, HOST_PATH_IN_THREADS, HOST_PATH_OUT_THREADS = 1, 2, 4
 
     def config(self, key, value):
         """mi355_deflate_ctx_config: range size / long-input threshold / where the sort takes its ranks from"""
@@ -635,6 +639,12 @@ class MultiGpu:
         if rc != OK:
             self._err(rc)
         return n.value
+
+    def stitch_info(self):
+        """how the packed ranges of the last call reached rank 0 ("rccl" / "peer"), and the ranks RCCL reports (0: no communicator)"""
+        a, b = C.c_int(0), C.c_int(0)
+        load().mi355_multi_stitch_info(self._h, C.byref(a), C.byref(b))
+        return {"stitch": "rccl" if a.value else "peer", "rccl_ranks": b.value}
 
     def trace(self):
         t = (C.c_double * 11)()

@@ -127,6 +127,16 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          in the first window, long periodic data) is encoded the other way without the caller noticing.
  *                          (Measuring aids, read once per process: the environment variables MI355_HOST_PLAN="1,2,3,3" -- rounds of
  *                          256 windows per piece -- and MI355_HOST_FIRST=<windows of the first piece, 0 = a whole round>.)
+ *   MI355_CFG_HOST_BOUNCE  what a host-buffer call does with PAGEABLE caller memory (a plain &[u8] / Vec<u8>: what
+ *                          deflate_bytes hands over, src/lib.rs:137-147) of 4 MiB or more: 1 (default) = the context's host
+ *                          threads copy it through page-locked slots, 1 MiB at a time -- the input's pieces arrive while the
+ *                          first ones are worked on, the finished bytes leave piece by piece, exactly as for a caller that
+ *                          page-locked its buffers; 0 = the runtime's own copies (one thread, in series with the kernels).
+ *                          Page-locked buffers (hipHostMalloc / hipHostRegister) never take the threads.
+ *   MI355_CFG_HOST_THREADS  how many such threads the context starts when the first pageable call comes (1..16; default 8 on
+ *                          a host of 32 hardware threads or more, else 4 or 2; the environment variable MI355_HOST_THREADS
+ *                          sets the default).  They sleep between calls; each owns 5 MiB of page-locked memory.
+ *                          MI355_E_STATE once they run.
  *   MI355_CFG_MULTI_STITCH  (of rank 0's context of a mi355_multi handle: mi355_multi_ctx(m, 0)) how the packed ranges of
  *                          mi355_deflate_encode_multi_device reach rank 0's device: 0 (default) = peer copies
  *                          (hipMemcpyPeerAsync: xGMI between the GPUs of a node), 1 = RCCL -- one ncclSend per rank, the
@@ -143,12 +153,15 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 #define MI355_CFG_HOST_STREAMING 4
 #define MI355_CFG_MULTI_STITCH 5
 #define MI355_CFG_STEPS_IN_EMIT 6
+#define MI355_CFG_HOST_BOUNCE 7
+#define MI355_CFG_HOST_THREADS 8
 int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers
  * in, host buffer out.  ctx may be NULL (the default context, see above).  An input of 16 MiB or more is
- * copied in up to four pieces and worked on while the later ones are still on the bus; that only overlaps when `in`
- * is page-locked (hipHostMalloc / hipHostRegister) -- pageable memory works, without the overlap.
+ * copied in pieces and worked on while the later ones are still on the bus, and its finished bytes leave piece by piece:
+ * for page-locked buffers (hipHostMalloc / hipHostRegister) on the copy engines directly, for pageable memory -- what a
+ * drop-in caller has -- through the context's host threads and their page-locked slots (MI355_CFG_HOST_BOUNCE).
  * Any in_len is taken, like src/lib.rs:137-147: an input of more than 1 GiB is walked as consecutive ranges of
  * 512 MiB (csrc/deflate_long.inc -- the phases of the sharded encode below, one range after the other on this
  * GPU; the same bytes as a single pass), which also bounds the device memory of a call: two workspaces of
@@ -197,8 +210,12 @@ typedef struct {
     uint32_t match_launches;        /* launches of the dominant kernel in this encode */
     float match_ms;                 /* their summed duration */
     uint32_t spec_repaired;         /* segments whose speculative entry was wrong and that were parsed again in place */
-    uint32_t reserved;
+    uint32_t host_path;             /* how the last host-buffer call (mi355_deflate_encode and its forms) moved its bytes:
+                                       MI355_HOST_PATH_* bits; 0 after a device-buffer call */
 } mi355_deflate_info;
+#define MI355_HOST_PATH_PIECES 1u      /* worked on and handed back piece by piece (MI355_CFG_HOST_STREAMING) */
+#define MI355_HOST_PATH_IN_THREADS 2u  /* pageable input: carried to the device by the context's host threads */
+#define MI355_HOST_PATH_OUT_THREADS 4u /* pageable output: carried back by them */
 int mi355_deflate_last_info(mi355_deflate_ctx* ctx, mi355_deflate_info* info);
 
 /* Diagnostics: the block layout of the last encode (type, BFINAL, tokens, input bytes, bit offset
@@ -289,7 +306,8 @@ uint32_t mi355_checksum_combine(int kind, uint32_t sum_a, uint32_t sum_b, uint64
  * MORE ranks than devices -- rank r lives on device r % n_devices, the ranks of a device run one after the other in
  * every phase, each with a context of its own -- up to 64 ranks (64 GiB with the default).  Beyond that the host-buffer
  * call goes through the single-device call of rank 0, which walks any length in ranges; the device-resident call,
- * whose shards the caller lays out, returns MI355_E_UNSUPPORTED (raise MI355_CFG_RANGE_BYTES: up to 3 GiB, 384 GiB).
+ * whose shards the caller lays out, returns MI355_E_UNSUPPORTED (raise MI355_CFG_RANGE_BYTES: a rank is clamped to what one
+ * pass addresses, just under 4 GiB -- reached at 2 GiB of MI355_CFG_RANGE_BYTES -- so 64 ranks take about 255 GiB).
  *   _encode_multi         host buffers in and out (ctx-less: the handle owns its contexts); wrapper 0 / 1 / 2 as in
  *              mi355_deflate_opts, `gz_hdr` = GzBuilder::into_header() for wrapper 2 (NULL: the blank header);
  *              out_cap >= mi355_deflate_bound_ex(in_len, wrapper, gz_len, 0); an input of less than 1 MiB per
@@ -305,7 +323,12 @@ uint32_t mi355_checksum_combine(int kind, uint32_t sum_a, uint32_t sum_b, uint64
  *              call has needed yet)
  *   _last_trace  rank 0's wall clock of the last call in ms: [0] bytes + tables, [1] wait, [2] entry + tokens,
  *              [3] wait, [4] block costs, [5] wait, [6] plan + pack + copy-out, [7] wait, [8] seams + framing,
- *              [9] host work of the exchanges (entries, token plan, tails, block plan, seams), [10] the whole call */
+ *              [9] host work of the exchanges (entries, token plan, tails, block plan, seams), [10] the whole call
+ *   _stitch_info  how the packed ranges of the last call reached rank 0: *by_rccl = 1 over ncclSend / ncclRecv
+ *              (MI355_CFG_MULTI_STITCH = 1, resident output), 0 by copies; *rccl_ranks = the ranks the communicator of rank 0's
+ *              device reports (one per distinct device of the handle), 0 when the handle holds none.  A stitch that fails on
+ *              one device ends the call with an error inside a bounded wait, aborts the communicators, and later calls of
+ *              the handle take the peer copies */
 typedef struct mi355_multi mi355_multi;
 int mi355_device_count(void); /* HIP devices this process sees (0: none, or no HIP runtime); for callers that do not link HIP */
 int mi355_multi_create(const int* devices, int n_devices, mi355_multi** out);
@@ -321,6 +344,7 @@ int mi355_deflate_encode_multi_device(mi355_multi* m, const void* const* d_ext, 
                                       const mi355_deflate_opts* opts, const uint8_t* gz_hdr, size_t gz_len, void* d_out,
                                       size_t out_cap, size_t* out_len);
 int mi355_multi_last_trace(const mi355_multi* m, double* ms, size_t cap);
+int mi355_multi_stitch_info(const mi355_multi* m, int* by_rccl, int* rccl_ranks);
 
 /* The gzip forms (cargo feature "gzip").  `hdr` = the bytes GzBuilder::into_header() returned: the
  * header comes from the crate gzip-header 1.0, which is not part of the reference tree, so the shim

@@ -1035,15 +1035,29 @@ def test_host_call_streamed_in_pieces(da):
                         continue
                     want = ob.encode(data, opts=ob.make_opts(c, l, m, wrapper)) if wrapper < 2 else ob.encode_gzip(
                         data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, m, 0))
+                    pieces = {}
                     for mode in (1, 0, 2):
                         ctx.config(da.Context.CFG_HOST_STREAMING, mode)
                         h_out.zero_()
                         n = ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), cap, da.CompressionOptions(c, l, m),
                                                 wrapper=wrapper)
                         assert bytes(h_out[:n].numpy()) == want, (name, lv, wrapper, mode, n, len(want))
+                        pieces[mode] = ctx.info()["host_path"]
+                    assert pieces[0] == 0 and pieces[1] == pieces[2] and pieces[1] in (0, da.Context.HOST_PATH_PIECES)
+                    if name == "text":
+                        assert pieces[1] == da.Context.HOST_PATH_PIECES
+                    if name in ("noise", "zeros"):
+                        assert pieces[1] == 0
                     ctx.config(da.Context.CFG_HOST_STREAMING, 1)
                     got = ctx.encode(data, da.CompressionOptions(c, l, m), wrapper=wrapper)  # pageable buffers
                     assert got == want, (name, lv, wrapper, "pageable", len(got), len(want))
+                    # the pageable call took the streamed form too: in and out through the context's host threads
+                    hp = ctx.info()["host_path"]
+                    P, I, O = da.Context.HOST_PATH_PIECES, da.Context.HOST_PATH_IN_THREADS, da.Context.HOST_PATH_OUT_THREADS
+                    assert hp & I, (name, lv, wrapper, hp)
+                    assert (hp & P) == pieces[1], (name, lv, wrapper, hp, pieces)  # (... exactly where the page-locked call did)
+                    if (hp & P) or len(want) >= (4 << 20):  # (a few KB of output -- zeros -- take the runtime's copy)
+                        assert hp & O, (name, lv, wrapper, hp)
         # an output buffer that is too small for the bound goes the single pass's way and says so only if the bytes do not fit
         data = cases[0][1]
         want = ob.encode(data, opts=ob.make_opts(*LV["default"], 0))
@@ -1055,6 +1069,96 @@ def test_host_call_streamed_in_pieces(da):
             ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), len(want) - 1, da.Compression.Default)
     finally:
         ctx.close()
+
+
+def test_pageable_host_buffers_through_the_host_threads(da):
+    """deflate_bytes(&[u8]) -> Vec<u8> (src/lib.rs:137-147,163) hands over pageable memory: from 4 MiB on the context's host
+    threads carry it through page-locked slots (deflate_bounce.inc, MI355_CFG_HOST_BOUNCE) -- same bytes as the runtime's own
+    copies, i.e. the oracle's; sizes around the 1 MiB chunks and the 16 MiB from which a call works in pieces; one thread and
+    many; page-locked buffers never take the threads; the call's error paths leave the threads idle (a buffer too small)."""
+    import numpy as np
+    import torch
+    P, I, O = da.Context.HOST_PATH_PIECES, da.Context.HOST_PATH_IN_THREADS, da.Context.HOST_PATH_OUT_THREADS
+    base = datagen.text_like(24_000_000, 0x9A6E) + datagen.rng_bytes(3_000_000, 0x9A6F) + datagen.mixed(21_000_000, 0x9A70)
+    c, l, m = LV["default"]
+    for threads in (1, 3, 0):
+        ctx = da.Context(0)
+        try:
+            if threads:
+                ctx.config(da.Context.CFG_HOST_THREADS, threads)
+            for n in (4 << 20, (4 << 20) - 1, (5 << 20) + 12345, (16 << 20) - 1, 16 << 20, (17 << 20) + 1, len(base)):
+                data = base[len(base) - n:]
+                want = ob.encode(data, opts=ob.make_opts(c, l, m, 0))
+                for bounce in (1, 0):
+                    ctx.config(da.Context.CFG_HOST_BOUNCE, bounce)
+                    p_in = np.frombuffer(data, dtype=np.uint8).copy()
+                    cap = da.bound(n) + 64
+                    p_out = np.full(cap, 0xEE, dtype=np.uint8)
+                    got_n = ctx.encode_host_ptr(p_in.ctypes.data, n, p_out.ctypes.data, cap, da.Compression.Default)
+                    assert bytes(p_out[:got_n]) == want, (threads, n, bounce, got_n, len(want))
+                    assert np.all(p_out[got_n:] == 0xEE), (threads, n, bounce)  # nothing written behind the stream
+                    hp = ctx.info()["host_path"]
+                    if bounce and n >= (4 << 20):
+                        assert hp & I, (threads, n, hp)
+                        assert bool(hp & O) == (len(want) >= (4 << 20) or bool(hp & P)), (threads, n, hp, len(want))
+                        assert bool(hp & P) == (n >= (16 << 20)), (threads, n, hp)
+                    else:
+                        assert not hp & (I | O), (threads, n, bounce, hp)
+            ctx.config(da.Context.CFG_HOST_BOUNCE, 1)
+            # zlib and gzip frames through the threads (the header bytes of a stream that left in pieces are put in on the host)
+            data = base[:40_000_000]
+            for wrapper in (1, 2):
+                want = ob.encode(data, opts=ob.make_opts(c, l, m, 1)) if wrapper == 1 else ob.encode_gzip(
+                    data, da.BLANK_GZIP_HEADER, opts=ob.make_opts(c, l, m, 0))
+                assert ctx.encode(data, da.Compression.Default, wrapper=wrapper) == want, wrapper
+                assert ctx.info()["host_path"] == P | I | O
+            # page-locked buffers: the copy engines directly
+            h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+            h_out = torch.empty(da.bound(len(data)) + 64, dtype=torch.uint8).pin_memory()
+            got_n = ctx.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), h_out.numel(), da.Compression.Default)
+            assert bytes(h_out[:got_n].numpy()) == ob.encode(data, opts=ob.make_opts(c, l, m, 0))
+            assert ctx.info()["host_path"] == P
+            # pageable in, page-locked out and the other way round
+            p_in = np.frombuffer(data, dtype=np.uint8).copy()
+            got_n = ctx.encode_host_ptr(p_in.ctypes.data, len(data), h_out.data_ptr(), h_out.numel(), da.Compression.Default)
+            assert bytes(h_out[:got_n].numpy()) == ob.encode(data, opts=ob.make_opts(c, l, m, 0)) and ctx.info()["host_path"] == P | I
+            p_out = np.zeros(h_out.numel(), dtype=np.uint8)
+            got_n = ctx.encode_host_ptr(h_in.data_ptr(), len(data), p_out.ctypes.data, p_out.size, da.Compression.Default)
+            assert bytes(p_out[:got_n]) == ob.encode(data, opts=ob.make_opts(c, l, m, 0)) and ctx.info()["host_path"] == P | O
+            # an output buffer that cannot hold the stream: an error, and the next call works
+            small = np.zeros(1_000_000, dtype=np.uint8)
+            with pytest.raises(da.DeflateError):
+                ctx.encode_host_ptr(p_in.ctypes.data, len(data), small.ctypes.data, small.size, da.Compression.Default)
+            assert ctx.encode(data[:9_000_000], da.Compression.Default) == ob.encode(data[:9_000_000], opts=ob.make_opts(c, l, m, 0))
+            # the levels without a hash read the whole input at once (rle, huffman_only), noise re-warms (Q1), zeros fall back
+            for lv, d2 in (("rle", bytes(20_000_000) + base[:5_000_000]), ("huffman_only", base[:18_000_000]),
+                           ("default", datagen.rng_bytes(19_000_000, 0x9A71)), ("default", bytes(33_000_000)), ("best", base[:20_000_000])):
+                cc, ll, mm = LV[lv]
+                assert ctx.encode(d2, da.CompressionOptions(cc, ll, mm)) == ob.encode(d2, opts=ob.make_opts(cc, ll, mm, 0)), lv
+        finally:
+            ctx.close()
+
+
+def test_multi_gpu_pinned_host_range_at_a_level_without_a_hash(da):
+    """Round-5 advisor finding: a rank's host range of 16 MiB or more arrives in pieces on the copy stream, and only the hashing
+    levels waited for it -- rle() and huffman_only() read the staging buffer with no ordering against the copy.  Pageable
+    buffers hid it (their copies are synchronous); page-locked ones must give the oracle's bytes too, call after call with
+    different data in the same staging buffer."""
+    import torch
+    m = da.MultiGpu([0, 0])
+    try:
+        for k, lv in enumerate(("rle", "huffman_only", "rle", "default")):
+            data = (datagen.text_like(20_000_000, 0xAD0 + k) + bytes(17_000_000) + datagen.mixed(13_000_000, 0xAE0 + k))[k:]
+            c, l, mt = LV[lv]
+            want = ob.encode(data, opts=ob.make_opts(c, l, mt, 0))
+            h_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+            cap = da.bound(len(data)) + 64
+            h_out = torch.zeros(cap, dtype=torch.uint8).pin_memory()
+            n = m.encode_host_ptr(h_in.data_ptr(), len(data), h_out.data_ptr(), cap, da.CompressionOptions(c, l, mt))
+            assert bytes(h_out[:n].numpy()) == want, (lv, n, len(want))
+            assert m.encode(data, da.CompressionOptions(c, l, mt)) == want, (lv, "pageable")
+    finally:
+        m.close()
 
 
 def test_long_input_walked_in_ranges(da, ctx, small_ranges):
