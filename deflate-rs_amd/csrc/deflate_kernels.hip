@@ -768,6 +768,13 @@ __global__ __launch_bounds__(1024) void k_lds_order_test(uint32_t rounds, uint32
 // MODE 0: ranks from ballots (sort_pass), 1: from returning atomics (sort_pass_rtn).  (A third form -- ONE pass in
 // position order with the bucket starts as cursors, the sixteen waves taking turns -- was measured at 0.51 ms against
 // 0.45 ms and is in the history of this file: DESIGN.md section 5.)
+#ifndef MI355_SWZ_BANKS
+#define MI355_SWZ_BANKS 14  // an epoch of whose sampled neighbours 64 sit on this many LDS banks or fewer is walked with the permuted
+                            // pair table (k_match3_swz); 0: never
+#endif
+#ifndef MI355_SWZ_PERSISTENT
+#define MI355_SWZ_PERSISTENT 0  // k_match3_swz: 1 = a workgroup per compute unit takes the marked epochs in turn, 0 = a workgroup per epoch
+#endif
 #ifndef MI355_SORT_P1
 #define MI355_SORT_P1 8
 #endif
@@ -948,6 +955,25 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
     __syncthreads();
     dbl &= 1u;
 #endif
+    // Do the epoch's sorted positions sit on few LDS banks?  Four times 64 neighbours of the sorted array -- the lanes of four of
+    // the walk's batches -- and the banks their pair-table entries fall in (address = 2 * position: bits 2..7): rows of records
+    // put them on sixteen, four, or one (PairWinT<true>); two such samples mark the epoch for k_match3_swz.
+    if (MI355_SWZ_BANKS) {
+        __syncthreads();
+        if (tid < 8) sRed[tid] = 0;
+        __syncthreads();
+        if (tid < 256 && J >= 1024) {  // at 1/8, 3/8, 5/8, 7/8 of the sorted array
+            const uint32_t q = tid >> 6;
+            const uint32_t bank = ((uint32_t)sH[(2 * q + 1) * (J / 8) + (tid & 63)] >> 1) & 63u;
+            atomicOr(&sRed[2 * q + (bank >> 5)], 1u << (bank & 31));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t few = 0;
+            for (int q = 0; q < 4; q++) few += (__popc(sRed[2 * q]) + __popc(sRed[2 * q + 1]) <= MI355_SWZ_BANKS) ? 1u : 0u;
+            Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2] = (J >= 1024 && few >= 2 && dbl) ? 1 : 0;
+        }
+    }
     uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
     const uint4* fin = reinterpret_cast<const uint4*>(sH);
     // dbl = 1: entries as 2 * position (k_match3 adds them to a pair-table address); positions are below 32768,
@@ -991,12 +1017,21 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 constexpr uint32_t M3T = 1024;
 constexpr uint32_t M3_PAIRS = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16: pairs in the table (= bytes staged)
 
-struct PairWin {
+// SWZ: the table with its 8-byte words permuted inside every 256 bytes -- word index XOR bits 11..15 of the address (byte 1 of
+// the address, masked: one SDWA `and` and one `xor`).  Rows of
+// records put the lanes of a wave (neighbours in a hash bucket = one row apart) on addresses a multiple of the row length
+// apart: 192 bytes between lanes is four of the LDS's 64 banks, 512 bytes one -- 0.84 of the LDS's cycles on such data were
+// bank conflicts, at 0.86 of the LDS busy and 0.35 of the vector ALU (tools/probes/lds_conflicts.sh).  Every address the walk
+// computes stays the plain one; only what is handed to the LDS is permuted (three vector instructions an address, which is
+// why a workgroup takes this form only for an epoch whose sorted positions sit on few banks: m3_few_banks).
+__device__ __forceinline__ uint32_t m3_swz(uint32_t a) { return a ^ ((a >> 8) & 0xF8u); }
+template <bool SWZ>
+struct PairWinT {
     const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array (entries are 2 * position)
-    uint32_t tbase;      // LDS address of T[0]
+    uint32_t tbase;      // LDS address of T[0] (a multiple of 256)
     typedef __attribute__((address_space(3))) const uint16_t* lds_u16;
     enum : uint32_t { SH = 1 };
-    __device__ uint32_t key_at(uint32_t a) const { return *(lds_u16)a; }
+    __device__ uint32_t key_at(uint32_t a) const { return *(lds_u16)(SWZ ? m3_swz(a) : a); }
     // 16 bytes from position pos on: the 40 aligned table bytes that hold T[pos & ~3 ...] are twenty pairs, every
     // other one of them -- the low half of each dword -- new bytes; five 8-byte reads (the 64-bank form), the
     // halves packed by byte selects, then the shift by pos & 3
@@ -1006,6 +1041,18 @@ struct PairWin {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x2 d0, d1, d2, d3, d4;
         const uint32_t a8 = (tbase + 2 * pos) & ~7u;
+        if (SWZ) {  // (five words, each where the permutation puts it: they may lie in two 256-byte blocks)
+            asm volatile(
+                "ds_read_b64 %0, %5\n\t"
+                "ds_read_b64 %1, %6\n\t"
+                "ds_read_b64 %2, %7\n\t"
+                "ds_read_b64 %3, %8\n\t"
+                "ds_read_b64 %4, %9\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4)
+                : "v"(m3_swz(a8)), "v"(m3_swz(a8 + 8)), "v"(m3_swz(a8 + 16)), "v"(m3_swz(a8 + 24)), "v"(m3_swz(a8 + 32))
+                : "memory");
+        } else
         asm volatile(
             "ds_read_b64 %0, %5\n\t"
             "ds_read_b64 %1, %5 offset:8\n\t"
@@ -1025,11 +1072,13 @@ struct PairWin {
         q[3] = __builtin_amdgcn_alignbyte(w4, w3, pos);
     }
     __device__ uint32_t load32(uint32_t pos) const {
+        if (SWZ) return key_at(tbase + 2 * pos) | (key_at(tbase + 2 * pos + 4) << 16);
         lds_u16 t = (lds_u16)(tbase + 2 * pos);
         return (uint32_t)t[0] | ((uint32_t)t[2] << 16);
     }
     __device__ uint32_t sidx(uint32_t i) const { return sb[(int64_t)(int32_t)i]; }
 };
+typedef PairWinT<false> PairWin;
 
 // Where the lanes of `dropped` stopped in their last group of eight steps: at the first probe that equals their key
 // (the compares of the step block shrank EXEC there) -> *any, the probe's address and how far offb is past its
@@ -1078,13 +1127,21 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
 #define MF_CMPW(F, N, T) "s_waitcnt lgkmcnt(" N ")\n\tv_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
 #define MF_CMPN(F, N, T) "v_cmpx_ne_u32_e32 vcc, %[" F T "], %[" F "probe]\n\t"
 #define MF_CMP(F, N, T) MF_CMPW(F, N, T)
-#define MF_ISSUE8(F, R0, R1, R2, R3)                                                                                 \
+#define MF_ADDS8(F, R0, R1, R2, R3)                                                                                  \
     MF_ADD(F, "a0", R3, "WORD_1") MF_ADD(F, "a1", R3, "WORD_0") MF_ADD(F, "a2", R2, "WORD_1") MF_ADD(F, "a3", R2, "WORD_0") \
-    MF_ADD(F, "a4", R1, "WORD_1") MF_ADD(F, "a5", R1, "WORD_0") MF_ADD(F, "a6", R0, "WORD_1") MF_ADD(F, "a7", R0, "WORD_0") \
+    MF_ADD(F, "a4", R1, "WORD_1") MF_ADD(F, "a5", R1, "WORD_0") MF_ADD(F, "a6", R0, "WORD_1") MF_ADD(F, "a7", R0, "WORD_0")
+// the eight reads: plain, or each at its permuted address (PairWinT<true>; worked out in the answer's own register)
+#define MF_RD8_0(F)                                                                                                  \
     "ds_read_u16 %[" F "t0], %[" F "a0]\n\tds_read_u16 %[" F "t1], %[" F "a1]\n\tds_read_u16 %[" F "t2], %[" F "a2]\n\t"    \
     "ds_read_u16 %[" F "t3], %[" F "a3]\n\tds_read_u16 %[" F "t4], %[" F "a4]\n\tds_read_u16 %[" F "t5], %[" F "a5]\n\t"    \
-    "ds_read_u16 %[" F "t6], %[" F "a6]\n\tds_read_u16 %[" F "t7], %[" F "a7]\n\t"                                       \
-    "v_add_u32_e32 %[" F "offb], -16, %[" F "offb]\n\t"
+    "ds_read_u16 %[" F "t6], %[" F "a6]\n\tds_read_u16 %[" F "t7], %[" F "a7]\n\t"
+#define MF_SW1(F, T, A)                                                                                                     \
+    "v_and_b32_sdwa %[" F T "], %[" F A "], %[m8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
+    "v_xor_b32_e32 %[" F T "], %[" F A "], %[" F T "]\n\tds_read_u16 %[" F T "], %[" F T "]\n\t"
+#define MF_RD8_1(F)                                                                                           \
+    MF_SW1(F, "t0", "a0") MF_SW1(F, "t1", "a1") MF_SW1(F, "t2", "a2") MF_SW1(F, "t3", "a3") MF_SW1(F, "t4", "a4") \
+    MF_SW1(F, "t5", "a5") MF_SW1(F, "t6", "a6") MF_SW1(F, "t7", "a7")
+#define MF_ISSUE8X(RD8, F, R0, R1, R2, R3) MF_ADDS8(F, R0, R1, R2, R3) RD8(F) "v_add_u32_e32 %[" F "offb], -16, %[" F "offb]\n\t"
 // the eight answers of a fibre in turn, then window and entries left; N0 = reads of the other fibre still behind them
 #if MI355_STEP_WAITS == 8
 #define MF_TEST8(F, N7, N6, N5, N4, N3, N2, N1, N0)                                                               \
@@ -1119,82 +1176,90 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     [F##t3] "=&v"(S.t3), [F##t4] "=&v"(S.t4), [F##t5] "=&v"(S.t5), [F##t6] "=&v"(S.t6), [F##t7] "=&v"(S.t7)
 #define MF_INS(F, S) [F##bb] "v"(S.bb2), [F##lowa] "v"(S.lowa2), [F##probe] "v"(S.probe), [F##endb] "v"(S.endb)
 
-template <bool HAS_Q>
-__device__ __forceinline__ void ms_steps_dual(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_t* sb8, uint64_t walkx, uint64_t walky,
-                                              uint64_t* stillx, uint64_t* stilly) {
-    uint64_t save, cx, cy;
-#define MF_ONE(F, W, C, RA, RB, R0, R1, R2, R3, R4, R5, R6, R7)                           \
+#define MF_ONE(RD8, F, W, C, RA, RB, R0, R1, R2, R3, R4, R5, R6, R7)                           \
         "s_mov_b64 exec, %[" W "]\n\t"                                                      \
         "global_load_dwordx4 " RA ", %[" F "offb], %[sb] offset:-14\n\t"                    \
         "global_load_dwordx4 " RB ", %[" F "offb], %[sb] offset:-30\n\t"                    \
         "s_waitcnt vmcnt(1)\n\t"                                                            \
-        MF_ISSUE8(F, R0, R1, R2, R3)                                                        \
+        MF_ISSUE8X(RD8, F, R0, R1, R2, R3)                                                        \
         MF_TEST8(F, "7", "6", "5", "4", "3", "2", "1", "0")                                 \
         "s_cbranch_execz .Lmf_one" F "%=\n\t"                                               \
         "s_waitcnt vmcnt(0)\n\t"                                                            \
-        MF_ISSUE8(F, R4, R5, R6, R7)                                                        \
+        MF_ISSUE8X(RD8, F, R4, R5, R6, R7)                                                        \
         MF_TEST8(F, "7", "6", "5", "4", "3", "2", "1", "0")                                 \
         ".Lmf_one" F "%=:\n\t"                                                              \
         "s_mov_b64 %[" C "], exec\n\t"
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        // towards the end of a pair of batches one fibre has often finished while the other still walks (a quarter of
-        // the blocks on text): its vector instructions would issue all the same -- an empty EXEC skips memory
-        // instructions, not vector ALU ones -- so a block for the fibre that is left
-        "s_mov_b64 %[cx], 0\n\t"
-        "s_mov_b64 %[cy], 0\n\t"
-        "s_cmp_eq_u64 %[wy], 0\n\t"
-        "s_cbranch_scc1 .Lmf_xonly%=\n\t"
-        "s_cmp_eq_u64 %[wx], 0\n\t"
-        "s_cbranch_scc1 .Lmf_yonly%=\n\t"
-        "s_mov_b64 exec, %[wx]\n\t"
-        "global_load_dwordx4 v[56:59], %[xoffb], %[sb] offset:-14\n\t"  // x: entries off-7 .. off
-        "global_load_dwordx4 v[60:63], %[xoffb], %[sb] offset:-30\n\t"  //    off-15 .. off-8
-        "s_mov_b64 exec, %[wy]\n\t"
-        "global_load_dwordx4 v[64:67], %[yoffb], %[sb] offset:-14\n\t"
-        "global_load_dwordx4 v[68:71], %[yoffb], %[sb] offset:-30\n\t"
-        "s_mov_b64 exec, %[wx]\n\t"
-        "s_waitcnt vmcnt(3)\n\t"
-        MF_ISSUE8("x", "v56", "v57", "v58", "v59")
-        "s_mov_b64 exec, %[wy]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        MF_ISSUE8("y", "v64", "v65", "v66", "v67")
-        "s_mov_b64 exec, %[wx]\n\t"
-        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8")
-        "s_mov_b64 %[cx], exec\n\t"
-        "s_mov_b64 exec, %[wy]\n\t"
-        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0")
-        "s_mov_b64 %[cy], exec\n\t"
-        "s_or_b64 vcc, %[cx], %[cy]\n\t"
-        "s_cbranch_scc0 .Lmf_end%=\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, %[cx]\n\t"
-        MF_ISSUE8("x", "v60", "v61", "v62", "v63")
-        "s_mov_b64 exec, %[cy]\n\t"
-        MF_ISSUE8("y", "v68", "v69", "v70", "v71")
-        "s_mov_b64 exec, %[cx]\n\t"
-        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8")
-        "s_mov_b64 %[cx], exec\n\t"
-        "s_mov_b64 exec, %[cy]\n\t"
-        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0")
-        "s_mov_b64 %[cy], exec\n\t"
-        "s_branch .Lmf_end%=\n\t"
-        ".Lmf_xonly%=:\n\t"
-        MF_ONE("x", "wx", "cx", "v[56:59]", "v[60:63]", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
-        "s_branch .Lmf_end%=\n\t"
-        ".Lmf_yonly%=:\n\t"
-        MF_ONE("y", "wy", "cy", "v[64:67]", "v[68:71]", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71")
-        ".Lmf_end%=:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        : MF_OPS(x, x), MF_OPS(y, y), [save] "=&s"(save), [cx] "=&s"(cx), [cy] "=&s"(cy)
-        : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky)
-        : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",
-          "v70", "v71");
-#undef MF_ONE
-    *stillx = cx;
-    *stilly = cy;
+
+// (towards the end of a pair of batches one fibre has often finished while the other still walks -- a quarter of the blocks on
+// text: its vector instructions would issue all the same, an empty EXEC skips memory instructions, not vector ALU ones -- so
+// a block for the fibre that is left: MF_ONE.  x: entries off-7 .. off in v[56:59], off-15 .. off-8 in v[60:63]; y: v[64:71].
+// Two instantiations: the plain table and the permuted one, PairWinT<true>.)
+#define MS_STEPS_DUAL_DEF(NAME, RD8) \
+template <bool HAS_Q> \
+__device__ __forceinline__ void NAME(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_t* sb8, uint64_t walkx, uint64_t walky, \
+                                              uint64_t* stillx, uint64_t* stilly) { \
+    uint64_t save, cx, cy; \
+    asm volatile( \
+        "s_mov_b64 %[save], exec\n\t" \
+ \
+ \
+ \
+        "s_mov_b64 %[cx], 0\n\t" \
+        "s_mov_b64 %[cy], 0\n\t" \
+        "s_cmp_eq_u64 %[wy], 0\n\t" \
+        "s_cbranch_scc1 .Lmf_xonly%=\n\t" \
+        "s_cmp_eq_u64 %[wx], 0\n\t" \
+        "s_cbranch_scc1 .Lmf_yonly%=\n\t" \
+        "s_mov_b64 exec, %[wx]\n\t" \
+        "global_load_dwordx4 v[56:59], %[xoffb], %[sb] offset:-14\n\t" \
+        "global_load_dwordx4 v[60:63], %[xoffb], %[sb] offset:-30\n\t" \
+        "s_mov_b64 exec, %[wy]\n\t" \
+        "global_load_dwordx4 v[64:67], %[yoffb], %[sb] offset:-14\n\t" \
+        "global_load_dwordx4 v[68:71], %[yoffb], %[sb] offset:-30\n\t" \
+        "s_mov_b64 exec, %[wx]\n\t" \
+        "s_waitcnt vmcnt(3)\n\t" \
+        MF_ISSUE8X(RD8, "x", "v56", "v57", "v58", "v59") \
+        "s_mov_b64 exec, %[wy]\n\t" \
+        "s_waitcnt vmcnt(1)\n\t" \
+        MF_ISSUE8X(RD8, "y", "v64", "v65", "v66", "v67") \
+        "s_mov_b64 exec, %[wx]\n\t" \
+        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8") \
+        "s_mov_b64 %[cx], exec\n\t" \
+        "s_mov_b64 exec, %[wy]\n\t" \
+        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0") \
+        "s_mov_b64 %[cy], exec\n\t" \
+        "s_or_b64 vcc, %[cx], %[cy]\n\t" \
+        "s_cbranch_scc0 .Lmf_end%=\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, %[cx]\n\t" \
+        MF_ISSUE8X(RD8, "x", "v60", "v61", "v62", "v63") \
+        "s_mov_b64 exec, %[cy]\n\t" \
+        MF_ISSUE8X(RD8, "y", "v68", "v69", "v70", "v71") \
+        "s_mov_b64 exec, %[cx]\n\t" \
+        MF_TEST8("x", "15", "14", "13", "12", "11", "10", "9", "8") \
+        "s_mov_b64 %[cx], exec\n\t" \
+        "s_mov_b64 exec, %[cy]\n\t" \
+        MF_TEST8("y", "7", "6", "5", "4", "3", "2", "1", "0") \
+        "s_mov_b64 %[cy], exec\n\t" \
+        "s_branch .Lmf_end%=\n\t" \
+        ".Lmf_xonly%=:\n\t" \
+        MF_ONE(RD8, "x", "wx", "cx", "v[56:59]", "v[60:63]", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63") \
+        "s_branch .Lmf_end%=\n\t" \
+        ".Lmf_yonly%=:\n\t" \
+        MF_ONE(RD8, "y", "wy", "cy", "v[64:67]", "v[68:71]", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71") \
+        ".Lmf_end%=:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, %[save]\n\t" \
+        : MF_OPS(x, x), MF_OPS(y, y), [save] "=&s"(save), [cx] "=&s"(cx), [cy] "=&s"(cy) \
+        : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky), [m8] "s"(0xF8u) \
+        : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", \
+          "v70", "v71"); \
+    *stillx = cx; \
+    *stilly = cy; \
 }
+MS_STEPS_DUAL_DEF(ms_steps_dual, MF_RD8_0)
+MS_STEPS_DUAL_DEF(ms_steps_dual_swz, MF_RD8_1)
+#undef MF_ONE
 
 constexpr uint32_t ADV_TILE = 1024, ADV_HALO = 260;
 struct TileM {
@@ -1206,19 +1271,18 @@ __device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, ui
     const uint64_t e = (uint64_t)seg_end(sg, base + r) - base;
     return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
 }
-template <bool HAS_Q>
-__global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
-                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
-                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
-                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
-                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
-    __shared__ __attribute__((aligned(16))) uint4 s_T[M3_PAIRS / 8];  // T[k] = byte k | byte k+1 << 8, k from the window's start
-    __shared__ uint32_t s_next;
+// One epoch (or one part of it) by one workgroup: the body of both kernels below.  SWZ: the permuted table (PairWinT<true>).
+template <bool HAS_Q, bool SWZ>
+__device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uint32_t e, const uint32_t part, const uint8_t* __restrict__ in, uint32_t n,
+                                         const uint16_t* __restrict__ Sg, const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                         uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16, SegEnds sg,
+                                         HashOverride ov, uint32_t split, uint32_t* __restrict__ Ms, uint32_t* __restrict__ Mqs,
+                                         uint32_t* __restrict__ sort_bad) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
     const uint64_t E = (uint64_t)e * WINDOW_SIZE;
     const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
     const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
+    const uint32_t tb0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_T;
     // stage the window: 16 bytes and the byte behind them make 16 pairs = two 16-byte stores
     for (uint32_t w = tid; w < wbytes / 16; w += M3T) {
         const uint64_t g = wbase + 16ull * w;
@@ -1240,8 +1304,15 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             o[2 * k] = __builtin_amdgcn_perm(t[k], t[k], 0x02010100u);          // b0 b1 | b1 b2
             o[2 * k + 1] = __builtin_amdgcn_perm(t[k + 1], t[k], 0x04030302u);  // b2 b3 | b3 b4
         }
-        s_T[2 * w] = make_uint4(o[0], o[1], o[2], o[3]);
-        s_T[2 * w + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        if (SWZ) {  // (8-byte words, each where the permutation puts it)
+            typedef __attribute__((address_space(3))) uint64_t* lds_u64;
+            const uint32_t a = tb0 + 32u * w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(lds_u64)m3_swz(a + 8u * k) = (uint64_t)o[2 * k] | ((uint64_t)o[2 * k + 1] << 32);
+        } else {
+            s_T[2 * w] = make_uint4(o[0], o[1], o[2], o[3]);
+            s_T[2 * w + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
     }
     const uint32_t J = epoch_active(n, E);
     const uint32_t nbat = (J + 63) / 64;
@@ -1255,12 +1326,11 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     __syncthreads();
-    const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)s_T;
+    const uint32_t tbase = tb0;
     const uint32_t bias = (uint32_t)(E - wbase);  // position of the own epoch's first byte in the window
     // (the array pointer may lie before the array for epoch 0; only indices >= 32768 - 7 are read then, and
     // the array has a pad in front)
     const uint16_t* sbase = Sg + (size_t)e * WINDOW_SIZE - WINDOW_SIZE;
-    PairWin win{sbase, tbase};
     const uint16_t* own = Sg + (size_t)e * WINDOW_SIZE;
     const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
     const uint16_t* Bprev = Bown - BSTRIDE;
@@ -1272,7 +1342,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t unordered = 0;
     // set a fibre up for batch b (all lanes call it: the lane masks it sets must be ballots of the whole wave)
     // (before0: the entry in front of the batch's first one, for the order check below)
-    auto set_up = [&](SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out, uint32_t before0, uint32_t* last_out) -> bool {
+    auto set_up = [&](const auto& win, SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out, uint32_t before0, uint32_t* last_out) -> bool {
         const uint32_t j = b * 64 + lane;
         const bool valid = have && j < J;
         uint32_t raw = 0, srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
@@ -1305,7 +1375,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return valid;
     };
     // settle the lanes of a fibre that left the last block
-    auto settle = [&](auto run1, SwG<HAS_Q>& st, uint64_t dropped) {
+    auto settle = [&](auto run1, const auto& win, SwG<HAS_Q>& st, uint64_t dropped) {
         uint64_t any;
         uint32_t asel, back;
         ms_decode(MsGroup{st.t0, st.t1, st.t2, st.t3, st.t4, st.t5, st.t6, st.t7, st.a0, st.a1, st.a2, st.a3, st.a4, st.a5,
@@ -1334,6 +1404,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     auto walk_all = [&](auto run1) {
         constexpr bool RUN1 = decltype(run1)::value;
+        const PairWinT<SWZ> win{sbase, tbase};
         uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
         for (;;) {
             uint32_t b = 0;
@@ -1345,8 +1416,8 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // (the entry in front of the pair's first one: a scalar load -- b is the same for the whole wave)
             uint32_t lastx, lasty;
             const uint32_t front = b ? (uint32_t)own[(uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 64 - 1))] : 0u;
-            const bool vx = set_up(sx, b, true, &srx, front, &lastx);
-            const bool vy = set_up(sy, b + 1, b + 1 < b_hi, &sry, lastx, &lasty);
+            const bool vx = set_up(win, sx, b, true, &srx, front, &lastx);
+            const bool vy = set_up(win, sy, b + 1, b + 1 < b_hi, &sry, lastx, &lasty);
             (void)lasty;
             M2_CNT(0, 2)
             M2_T(8)
@@ -1375,7 +1446,10 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 M2_CNT(1, 1)
                 M2_CNT(7, __popcll(wx) + __popcll(wy))
                 uint64_t cx, cy;
-                ms_steps_dual(sx, sy, sb8u, wx, wy, &cx, &cy);
+                if (SWZ)
+                    ms_steps_dual_swz(sx, sy, sb8u, wx, wy, &cx, &cy);
+                else
+                    ms_steps_dual(sx, sy, sb8u, wx, wy, &cx, &cy);
                 M2_T(12)
                 sx.walk = cx;
                 sy.walk = cy;
@@ -1383,8 +1457,8 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 // for lane values -- two moves, two bit-selects, a 64-bit compare and two read-first-lanes per round)
                 uint64_t dx, dy;
                 asm("s_andn2_b64 %0, %2, %3\n\ts_andn2_b64 %1, %4, %5" : "=&s"(dx), "=&s"(dy) : "s"(wx), "s"(cx), "s"(wy), "s"(cy) : "scc");
-                if (dx) settle(run1, sx, dx);
-                if (dy) settle(run1, sy, dy);
+                if (dx) settle(run1, win, sx, dx);
+                if (dy) settle(run1, win, sy, dy);
                 M2_T(9)
             }
             swg_result(sx, &pxm, &pxq);
@@ -1402,7 +1476,7 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (HAS_Q) Mqo[E + pyat] = pyq;
         }
     };
-    if (__builtin_amdgcn_readfirstlane((int)Bown[WINDOW_SIZE + 1]))
+    if (!SWZ && __builtin_amdgcn_readfirstlane((int)Bown[WINDOW_SIZE + 1]))  // (rows of records are no runs of one byte)
         walk_all(std::true_type{});
     else
         walk_all(std::false_type{});
@@ -1433,6 +1507,47 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifdef MI355_MATCH_STATS
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], (unsigned long long)m2c[i]);
+#endif
+}
+
+constexpr uint32_t M3_TABLE_U4 = (M3_PAIRS * 2 + 255) / 256 * 16;  // the table in uint4: whole 256-byte blocks (PairWinT<true>)
+// a workgroup per epoch (or per part of one: small inputs).  Epochs that k_sort marked for the permuted table are left to
+// k_match3_swz.
+template <bool HAS_Q>
+__global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
+                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
+                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
+    __shared__ __attribute__((aligned(256))) uint4 s_T[M3_TABLE_U4];  // T[k] = byte k | byte k+1 << 8, k from the window's start
+    __shared__ uint32_t s_next;
+    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
+    if (MI355_SWZ_BANKS && __builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2])) return;
+    m3_epoch<HAS_Q, false>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+}
+// The epochs of [e0, e0 + ne) that k_sort marked -- their sorted positions sit on few LDS banks: rows of records -- with the
+// permuted table; a workgroup per compute unit takes the marked epochs in turn (text has none: the launch is 256 workgroups
+// that read a dozen flags each and leave).
+template <bool HAS_Q>
+__global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3_swz(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
+                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t units, uint32_t split,
+                                                uint32_t* __restrict__ Ms, uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
+    __shared__ __attribute__((aligned(256))) uint4 s_T[M3_TABLE_U4];
+    __shared__ uint32_t s_next;
+#if MI355_SWZ_PERSISTENT
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {  // units: epochs x parts
+        const uint32_t e = e0 + u / split;
+        if (!__builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2])) continue;
+        __syncthreads();  // (the unit before is done with the LDS)
+        m3_epoch<HAS_Q, true>(s_T, s_next, e, u % split, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+    }
+#else
+    (void)units;
+    const uint32_t e = e0 + blockIdx.x / split;
+    if (!__builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2])) return;
+    m3_epoch<HAS_Q, true>(s_T, s_next, e, blockIdx.x % split, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
 #endif
 }
 

@@ -9,7 +9,7 @@ import datagen, deflate_amd as da, oracle_binding as ob
 
 
 def make_data(rnd):
-    kind = rnd.choice(["text", "mixed", "rng", "zeros", "period", "lowent", "runs"])
+    kind = rnd.choice(["text", "mixed", "rng", "zeros", "period", "lowent", "runs", "records"])
     n = rnd.choice([0, 1, 2, 3, 5, 100, 1000, 31744, 32768, 65536, 65794]) if rnd.random() < 0.15 else rnd.randrange(1, 400000)
     seed = rnd.randrange(1 << 30)
     if n == 0:
@@ -22,6 +22,20 @@ def make_data(rnd):
         d = datagen.rng_bytes(n, seed)
     elif kind == "zeros":
         d = bytes(n)
+    elif kind == "records":  # rows of one length that differ in a counter and a few narrow fields (k_match3_swz's epochs), between text
+        import numpy as np
+        width = rnd.choice([24, 40, 48, 64, 96, 100, 128, 256, 512, 1000])
+        r = np.random.default_rng(seed)
+        rows = n // width + 1
+        a = np.tile(r.integers(0, 256, size=width, dtype=np.uint8), (rows, 1))
+        a[:, 4:8] = np.arange(rows, dtype=np.uint32).view(np.uint8).reshape(rows, 4)
+        cols = r.choice(np.arange(8, width), size=max(1, width // 8), replace=False)
+        a[:, cols] = r.integers(0, 16, size=(rows, len(cols)), dtype=np.uint8)
+        d = a.reshape(-1)[:n].tobytes()
+        if rnd.random() < 0.5:
+            k = rnd.randrange(0, max(1, n // 2))
+            d = d[:k] + datagen.text_like(min(60000, n), seed ^ 5)[: n - k if n - k < 60000 else 60000] + d[k:]
+            d = d[:n]
     elif kind == "period":
         per = rnd.choice([1, 2, 3, 7, 300, 4099, 32768, 32769])
         d = (datagen.rng_bytes(per, seed) * (n // per + 1))[:n]
