@@ -275,6 +275,55 @@ def self_launch(args, argv):
     return subprocess.call(plan["cmd"], env=env)
 
 
+def live_pmc(args, size, lvl, dominant):
+    """The dominant kernel's counters from THIS box, now: three rocprofv3 --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE -- the
+    TCC counters do not fit one pass; MI355X_MICROARCH.md, HBM section) over one step of this very command.  Per launch; FETCH_SIZE
+    doubled as the guide prescribes for gfx950.  None when rocprofv3 is not there or a pass fails (the line then falls back to the
+    committed summary and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("MI355_BENCH_LIVE_PMC", "1") == "0":
+        return None
+    passes = [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"], ["FETCH_SIZE"],
+              ["WRITE_SIZE"]]
+    tot = {}
+    launches = {}
+    t0 = time.perf_counter()
+    for counters in passes:
+        d = tempfile.mkdtemp(prefix="mi355_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "1",
+                                           "--warmup", "0", "--no-cpu-baseline", "--no-host-api", "--no-live-pmc", "--workload", args.workload,
+                                           "--size", str(size), "--level", lvl]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            seen = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"].replace("void ", "").replace("mi355::", "")
+                    if not name.startswith(dominant):  # (k_match3 and k_match3_swz: the walk, whichever table an epoch took)
+                        continue
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    seen.setdefault(r["Counter_Name"], set()).add(r["Dispatch_Id"])
+            for cn in counters:
+                if cn not in seen:
+                    return None
+                launches[cn] = len(seen[cn])
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {"hbm_bytes": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
+           "SQ_INSTS_VALU": tot["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": tot["SQ_ACTIVE_INST_VALU"], "GRBM_GUI_ACTIVE": tot["GRBM_GUI_ACTIVE"],
+           "lds_bank_conflict_rate": round(tot["SQ_LDS_BANK_CONFLICT"] / max(1.0, tot["SQ_LDS_IDX_ACTIVE"]), 4),
+           "valu_wave_instr_per_input_byte": round(tot["SQ_INSTS_VALU"] / size, 3), "dispatches": launches,
+           "seconds": round(time.perf_counter() - t0, 1)}
+    return out
+
+
 def committed_digest(workload, total, lvl):
     """length and SHA-256 of the ORACLE's stream of this very input, where one is committed (tests/golden/)"""
     if workload != "webtext" or lvl != "default":
@@ -331,7 +380,10 @@ def main(argv=None):
     ap.add_argument("--stitch", default="rccl", choices=["rccl", "peer"],
                     help="--single-process: how the packed ranges reach rank 0's device (MI355_CFG_MULTI_STITCH)")
     ap.add_argument("--dry-run", action="store_true", help="N > 1 without torch.distributed.run: print the launch as JSON and stop")
-    ap.add_argument("--pmc-file", default="", help="PMC summary to take roofline.traffic from (default: newest profiles/r*_pmc_summary.json)")
+    ap.add_argument("--pmc-file", default="", help="PMC summary to take roofline.traffic from when no live counters are taken (default: "
+                                                    "newest profiles/r*_pmc_summary.json)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the three rocprofv3 --pmc passes that measure roofline.traffic / valu_issue on this box (about a minute)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -521,27 +573,38 @@ def main(argv=None):
         lds_conflict = None
         pmc_source = None
         valu_issue = None
-        try:
-            import glob
-            cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            pm = json.load(open(cands[-1]))
-            k = pm["kernels"][dominant]
-            # a summary is only taken when it is of this very workload and every counter of the kernel was
-            # averaged over launches of ONE shape: launches == steps of the profiled command (the host-API leg,
-            # which launches the kernel on pieces of the input, must have been off)
-            if (pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1
-                    and pm.get("launches_per_pass") == k.get("launches") and k.get("launches")):
-                traffic = k["hbm_bytes"]
-                lds_conflict = k.get("lds_bank_conflict_rate")
-                pmc_source = os.path.relpath(cands[-1], ROOT)
-                # what the kernel is really bound by (the contract's "bound" knows hbm and mfma only): vector-ALU issue.
-                # A wave64 instruction holds its SIMD for four cycles; busy = issued wave instructions x 4 over the cycles
-                # of the chip's 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-                if k.get("SQ_ACTIVE_INST_VALU") and k.get("GRBM_GUI_ACTIVE"):
-                    valu_issue = {"wave_instr_per_input_byte": k.get("valu_wave_instr_per_input_byte"),
-                                  "busy": round(k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0), 3)}
-        except Exception:
-            pass
+        live = None
+        if world == 1 and not args.no_live_pmc and dominant in ("k_match3", "k_rle"):
+            live = live_pmc(args, size, lvl, dominant)
+        if live is not None:
+            traffic = live["hbm_bytes"]
+            lds_conflict = live["lds_bank_conflict_rate"]
+            pmc_source = ("live: three rocprofv3 --pmc passes over one step of this command on this box, %.0f s (FETCH_SIZE x 2 + WRITE_SIZE; "
+                          "%s launches of the kernel per pass)" % (live["seconds"], sorted(set(live["dispatches"].values()))))
+            valu_issue = {"wave_instr_per_input_byte": live["valu_wave_instr_per_input_byte"],
+                          "busy": round(live["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (live["GRBM_GUI_ACTIVE"] / 8.0), 3)}
+        else:
+          try:
+              import glob
+              cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+              pm = json.load(open(cands[-1]))
+              k = pm["kernels"][dominant]
+              # a summary is only taken when it is of this very workload and every counter of the kernel was
+              # averaged over launches of ONE shape: launches == steps of the profiled command (the host-API leg,
+              # which launches the kernel on pieces of the input, must have been off)
+              if (pm["workload"] == args.workload and pm["bytes_per_gpu"] == size and pm["level"] == lvl and world == 1
+                      and pm.get("launches_per_pass") == k.get("launches") and k.get("launches")):
+                  traffic = k["hbm_bytes"]
+                  lds_conflict = k.get("lds_bank_conflict_rate")
+                  pmc_source = os.path.relpath(cands[-1], ROOT)
+                  # what the kernel is really bound by (the contract's "bound" knows hbm and mfma only): vector-ALU issue.
+                  # A wave64 instruction holds its SIMD for four cycles; busy = issued wave instructions x 4 over the cycles
+                  # of the chip's 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                  if k.get("SQ_ACTIVE_INST_VALU") and k.get("GRBM_GUI_ACTIVE"):
+                      valu_issue = {"wave_instr_per_input_byte": k.get("valu_wave_instr_per_input_byte"),
+                                    "busy": round(k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0), 3)}
+          except Exception:
+              pass
         # the kernel that reads the input coalesced: k_sort files every position under its hash (reads n, writes
         # the sorted array and the bucket starts, 2 B per position each); on the unsorted path k_links_a
         links_ms = stage_ms.get("links", 0.0) / args.steps if stage_ms else 0.0

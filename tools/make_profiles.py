@@ -33,7 +33,7 @@ def rocprof(args, sub):
     d = os.path.join(OUT, "%s_%s" % (TAG, sub))
     subprocess.run("rm -rf " + d, shell=True)
     cmd = ["rocprofv3"] + args + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                                  "--no-cpu-baseline", "--no-host-api"] + EXTRA
+                                  "--no-cpu-baseline", "--no-host-api", "--no-live-pmc"] + EXTRA
     subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     return d
 
@@ -78,7 +78,7 @@ def main():
     wr = pmc(["WRITE_SIZE"], None)
     # the bench line of an unprofiled run
     EXTRA = base_extra + ["--steps", "5", "--warmup", "2"]
-    line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-file", "/nonexistent"] + EXTRA, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+    line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-live-pmc", "--pmc-file", "/nonexistent"] + EXTRA, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
     open(os.path.join(OUT, TAG + "_bench.json"), "w").write(line + "\n")
     bl = json.loads(line)
     n = bl["config"]["bytes_per_gpu"]
