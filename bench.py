@@ -224,9 +224,19 @@ def single_process(args):
         for i in range(0, n, 256 << 20):
             yield bytes(d_out[i:min(n, i + (256 << 20))].cpu().numpy())
     res.update(stream_check(args.workload, total, size, N, lvl, parts, n))
-    m.close()  # (RCCL says goodbye on stdout when its communicators go: the line comes last)
-    sys.stdout.flush()
+    m.close()
     print(json.dumps(res))
+    quiet_stdout()
+
+
+def quiet_stdout():
+    """The JSON line is the last thing on stdout: librccl prints its version banner there when the process exits (every rank's
+    lands on the launcher's stdout) -- from here on file descriptor 1 is /dev/null."""
+    sys.stdout.flush()
+    try:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    except OSError:
+        pass
 
 
 def device_count():
@@ -726,8 +736,8 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(res))  # (the line comes last on stdout, behind anything the communicators print when they go)
+        print(json.dumps(res))
+    quiet_stdout()
 
 
 if __name__ == "__main__":

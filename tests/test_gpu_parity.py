@@ -1930,6 +1930,30 @@ def test_two_contexts_two_threads(da):
     for t in ts:
         t.join()
     assert not errs
+    # ... and with pageable buffers large enough for each context's own host threads and rings (deflate_bounce.inc): two sets of
+    # threads at work at once, calls of different sizes back to back (the rings wrap, sessions open and close)
+    big = [datagen.text_like(23_000_000, 23), datagen.text_like(9_000_000, 24) + datagen.rng_bytes(2_000_000, 25)]
+    bigrefs = [ob.encode(d, level=ob.DEFAULT) for d in big]
+
+    def work2(i):
+        c = da.Context(0)
+        try:
+            for k in range(6):
+                d = big[(i + k) % 2]
+                if c.encode(d) != bigrefs[(i + k) % 2]:
+                    errs.append(("pageable", i, k))
+                cut = 4_500_000 + 333_333 * k
+                if c.encode(d[:cut]) != ob.encode(d[:cut], level=ob.DEFAULT):
+                    errs.append(("pageable cut", i, k))
+        finally:
+            c.close()
+
+    ts = [threading.Thread(target=work2, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
 
 
 # the plain-C example over the ABI (examples/mi355_deflate_cli.c), built with gcc and run as a process
