@@ -129,14 +129,15 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          256 windows per piece -- and MI355_HOST_FIRST=<windows of the first piece, 0 = a whole round>.)
  *   MI355_CFG_HOST_BOUNCE  what a host-buffer call does with PAGEABLE caller memory (a plain &[u8] / Vec<u8>: what
  *                          deflate_bytes hands over, src/lib.rs:137-147) of 4 MiB or more: 1 (default) = the context's host
- *                          threads copy it through page-locked slots, 1 MiB at a time -- the input's pieces arrive while the
- *                          first ones are worked on, the finished bytes leave piece by piece, exactly as for a caller that
- *                          page-locked its buffers; 0 = the runtime's own copies (one thread, in series with the kernels).
- *                          Page-locked buffers (hipHostMalloc / hipHostRegister) never take the threads.
+ *                          threads copy it through two page-locked rings of 64 MiB -- the input's pieces arrive while the
+ *                          first ones are worked on, the finished bytes leave piece by piece, as for a caller that page-locked
+ *                          its buffers; 0 = the runtime's own copies (one thread, in series with the kernels).
+ *                          Page-locked buffers (hipHostMalloc / hipHostRegister) never take the threads.  The same threads
+ *                          carry the ranges of a call of more than 1 GiB and of mi355_deflate_encode_multi.
  *   MI355_CFG_HOST_THREADS  how many such threads the context starts when the first pageable call comes (1..16; default 8 on
  *                          a host of 32 hardware threads or more, else 4 or 2; the environment variable MI355_HOST_THREADS
- *                          sets the default).  They sleep between calls; each owns 5 MiB of page-locked memory.
- *                          MI355_E_STATE once they run.
+ *                          sets the default).  They stay on the memory node of the thread that made them, poll for a
+ *                          millisecond after a call and sleep between calls.  MI355_E_STATE once they run.
  *   MI355_CFG_MULTI_STITCH  (of rank 0's context of a mi355_multi handle: mi355_multi_ctx(m, 0)) how the packed ranges of
  *                          mi355_deflate_encode_multi_device reach rank 0's device: 0 (default) = peer copies
  *                          (hipMemcpyPeerAsync: xGMI between the GPUs of a node), 1 = RCCL -- one ncclSend per rank, the
