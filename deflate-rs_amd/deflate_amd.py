@@ -616,7 +616,7 @@ class MultiGpu:
         rc = load().mi355_deflate_encode_multi(self._h, data, len(data), C.byref(o), hdr, len(hdr) if hdr else 0, out, cap, C.byref(n))
         if rc != OK:
             self._err(rc)
-        return bytes(out[:n.value])
+        return bytes(memoryview(out)[: n.value])
 
     def encode_host_ptr(self, in_ptr, n, out_ptr, out_cap, options=Compression.Default, wrapper=0):
         o = CompressionOptions.from_(options).to_c(wrapper, 0, FLUSH_FINISH)
