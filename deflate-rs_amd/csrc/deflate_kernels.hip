@@ -957,7 +957,7 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 #endif
     // Do the epoch's sorted positions sit on few LDS banks?  Four times 64 neighbours of the sorted array -- the lanes of four of
     // the walk's batches -- and the banks their pair-table entries fall in (address = 2 * position: bits 2..7): rows of records
-    // put them on sixteen, four, or one (PairWinT<true>); two such samples mark the epoch for k_match3_swz.
+    // put them on sixteen, four, or one (PairWinT<true>); two such samples, or one on half as many, mark the epoch for k_match3_swz.
     if (MI355_SWZ_BANKS) {
         __syncthreads();
         if (tid < 8) sRed[tid] = 0;
@@ -969,9 +969,15 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
         }
         __syncthreads();
         if (tid == 0) {
-            uint32_t few = 0;
-            for (int q = 0; q < 4; q++) few += (__popc(sRed[2 * q]) + __popc(sRed[2 * q + 1]) <= MI355_SWZ_BANKS) ? 1u : 0u;
-            Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2] = (J >= 1024 && few >= 2 && dbl) ? 1 : 0;
+            // (two samples on few banks, or one on very few: an epoch that is left to k_match3 among marked ones is a workgroup
+            // that runs a millisecond by itself while the other kernel waits)
+            uint32_t few = 0, very = 0;
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nb = (uint32_t)(__popc(sRed[2 * q]) + __popc(sRed[2 * q + 1]));
+                few += nb <= MI355_SWZ_BANKS ? 1u : 0u;
+                very += nb <= MI355_SWZ_BANKS / 2 ? 1u : 0u;
+            }
+            Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2] = (J >= 1024 && (few >= 2 || very >= 1) && dbl) ? 1 : 0;
         }
     }
     uint4* out = reinterpret_cast<uint4*>(Sg + (size_t)e * WINDOW_SIZE);
