@@ -1023,14 +1023,13 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 constexpr uint32_t M3T = 1024;
 constexpr uint32_t M3_PAIRS = 2 * WINDOW_SIZE + 258 + 14;  // a multiple of 16: pairs in the table (= bytes staged)
 
-// SWZ: the table with its 8-byte words permuted inside every 256 bytes -- word index XOR bits 11..15 of the address (byte 1 of
-// the address, masked: one SDWA `and` and one `xor`).  Rows of
+// SWZ: the table with its 8-byte words permuted inside every 256 bytes -- word index XOR bits 8..12 of the address.  Rows of
 // records put the lanes of a wave (neighbours in a hash bucket = one row apart) on addresses a multiple of the row length
 // apart: 192 bytes between lanes is four of the LDS's 64 banks, 512 bytes one -- 0.84 of the LDS's cycles on such data were
 // bank conflicts, at 0.86 of the LDS busy and 0.35 of the vector ALU (tools/probes/lds_conflicts.sh).  Every address the walk
 // computes stays the plain one; only what is handed to the LDS is permuted (three vector instructions an address, which is
-// why a workgroup takes this form only for an epoch whose sorted positions sit on few banks: m3_few_banks).
-__device__ __forceinline__ uint32_t m3_swz(uint32_t a) { return a ^ ((a >> 8) & 0xF8u); }
+// why a workgroup takes this form only for an epoch whose sorted positions sit on few banks: k_sort's mark).  The permutation
+// itself is stages.h m3_swz (pinned on the CPU: tests/test_stages_vs_oracle.py).
 template <bool SWZ>
 struct PairWinT {
     const uint16_t* sb;  // global: index 0 = entry 0 of the previous epoch's sorted array (entries are 2 * position)
@@ -1141,8 +1140,8 @@ __device__ __forceinline__ void ms_decode(const MsGroup st, uint64_t* any_out, u
     "ds_read_u16 %[" F "t0], %[" F "a0]\n\tds_read_u16 %[" F "t1], %[" F "a1]\n\tds_read_u16 %[" F "t2], %[" F "a2]\n\t"    \
     "ds_read_u16 %[" F "t3], %[" F "a3]\n\tds_read_u16 %[" F "t4], %[" F "a4]\n\tds_read_u16 %[" F "t5], %[" F "a5]\n\t"    \
     "ds_read_u16 %[" F "t6], %[" F "a6]\n\tds_read_u16 %[" F "t7], %[" F "a7]\n\t"
-#define MF_SW1(F, T, A)                                                                                                     \
-    "v_and_b32_sdwa %[" F T "], %[" F A "], %[m8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
+#define MF_SW1(F, T, A)                                                                                   \
+    "v_lshrrev_b32_e32 %[" F T "], 5, %[" F A "]\n\tv_and_b32_e32 %[" F T "], 0xf8, %[" F T "]\n\t"       \
     "v_xor_b32_e32 %[" F T "], %[" F A "], %[" F T "]\n\tds_read_u16 %[" F T "], %[" F T "]\n\t"
 #define MF_RD8_1(F)                                                                                           \
     MF_SW1(F, "t0", "a0") MF_SW1(F, "t1", "a1") MF_SW1(F, "t2", "a2") MF_SW1(F, "t3", "a3") MF_SW1(F, "t4", "a4") \
@@ -1257,7 +1256,7 @@ __device__ __forceinline__ void NAME(SwG<HAS_Q>& x, SwG<HAS_Q>& y, const uint16_
         "s_waitcnt vmcnt(0)\n\t" \
         "s_mov_b64 exec, %[save]\n\t" \
         : MF_OPS(x, x), MF_OPS(y, y), [save] "=&s"(save), [cx] "=&s"(cx), [cy] "=&s"(cy) \
-        : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky), [m8] "s"(0xF8u) \
+        : MF_INS(x, x), MF_INS(y, y), [sb] "s"(sb8), [wx] "s"(walkx), [wy] "s"(walky) \
         : "vcc", "scc", "memory", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", \
           "v70", "v71"); \
     *stillx = cx; \

@@ -873,6 +873,15 @@ MI355_HD void swg_result(const SwG<HAS_Q>& s, uint32_t* m, uint32_t* mq) {
     *mq = (HAS_Q && lf_me(s.hq)) ? s.mq : r;
 }
 
+// ---- the permuted pair table (k_match3_swz; deflate_kernels.hip PairWinT<true>) --------------------------------------------
+// LDS address -> where the permuted table keeps that byte: the index of the 8-byte word inside its 256-byte block (address
+// bits 3..7) XOR address bits 8..12.  A bijection of every 256-byte block onto itself that moves whole 8-byte words, so an
+// aligned read of up to eight bytes finds its bytes together; lanes whose addresses differ by a multiple of 128, 192, 256 or
+// 512 bytes -- rows of records -- land on different banks.  (The table starts at a multiple of 256 and is whole blocks long.
+// Bits 11..15 instead -- byte 1 of the address, masked: one SDWA instruction less per read -- spread rows of 64 and 128 bytes
+// over eight banks only.)
+MI355_HD uint32_t m3_swz(uint32_t a) { return a ^ ((a >> 5) & 0xF8u); }
+
 // ---- rle (rle.rs:13-18, 46-53) ------------------------------------------------------------
 // R[p] = number of bytes from p equal to data[p-1], capped at 258 and at the end of input; 0 if
 // p == 0 or data[p] != data[p-1].

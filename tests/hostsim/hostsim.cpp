@@ -622,6 +622,7 @@ int hostsim_encode(const uint8_t* in, uint64_t n, uint32_t checks, uint32_t lazy
 }
 
 void hostsim_use_multi(int on) { g_multi = on; }
+uint32_t hostsim_swz(uint32_t a) { return m3_swz(a); }  // the permuted pair table's address map (k_match3_swz)
 void hostsim_force_ident(int on) { g_force_ident = on; }
 
 // expose M for diffing: longest_match(prev_length=0) for every position

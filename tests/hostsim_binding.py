@@ -50,6 +50,13 @@ def encode(data, checks, lazy_lt, matching_type, seg=0, fan=4):
     return rc, bytes(memoryview(out)[: olen.value]) if rc == 0 else b"", flags.value, bl
 
 
+def swz(a):
+    """stages.h m3_swz: where the permuted pair table keeps the byte of LDS address a"""
+    L = lib()
+    L.hostsim_swz.restype = C.c_uint32
+    return int(L.hostsim_swz(C.c_uint32(a)))
+
+
 def use_multi(on):
     """switch the match stage to match_walk_multi (the formulation k_match runs)"""
     lib().hostsim_use_multi(int(on))

@@ -218,3 +218,22 @@ def test_code_length_rle_run_by_run_equals_the_state_machine():
         cases.append(bytes(out[:316]))
     for lens in cases:
         assert hs.rle_forms_agree(lens) == 0, list(lens)
+
+
+def test_permuted_pair_table_is_a_word_permutation_of_every_256_bytes():
+    """k_match3_swz keeps the pair table with the 8-byte words of every 256-byte block permuted (stages.h m3_swz).  What the walk
+    relies on: a bijection of each block onto itself, whole 8-byte words moved (an aligned read of up to 8 bytes stays together),
+    and rows of records -- lanes 192 or 512 bytes apart -- spread over the LDS's 64 four-byte banks instead of 4 or 1."""
+    size = 132 * 1024  # (the table: 2 x 32768 + 272 pairs, rounded up to whole blocks)
+    img = [hs.swz(a) for a in range(0, size, 8)]
+    for blk in range(0, size, 256):
+        words = img[blk // 8:(blk + 256) // 8]
+        assert sorted(words) == list(range(blk, blk + 256, 8)), blk
+    for a in (0, 8, 1000, 2047, 2048, 65535, 131071):
+        assert hs.swz(a) & 7 == a & 7 and hs.swz(a) >> 8 == a >> 8
+    for stride, least in ((128, 24), (192, 24), (256, 24), (512, 16), (1024, 8)):  # rows of 64 / 96 / 128 / 256 / 512 bytes
+        for base in (0, 6, 1234, 60000):
+            plain = {((base + stride * i) >> 2) & 63 for i in range(64) if base + stride * i < size}
+            perm = {(hs.swz(base + stride * i) >> 2) & 63 for i in range(64) if base + stride * i < size}
+            assert len(plain) <= 8 and len(perm) >= least, (stride, base, len(plain), len(perm))
+
