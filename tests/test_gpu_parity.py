@@ -1183,7 +1183,7 @@ def test_rows_of_records_take_the_permuted_pair_table(da, ctx):
         cols = r.choice(np.arange(8, width), size=max(1, width // 8), replace=False)
         a[:, cols] = r.integers(0, 16, size=(rows, len(cols)), dtype=np.uint8)
         return a.reshape(-1)[:n].tobytes()
-    for width, n in ((96, 3_000_000), (256, 3_000_001), (1024, 2_500_000), (48, 2_000_000), (40, 2_000_000), (97, 1_500_000)):
+    for width, n in ((96, 3_000_000), (256, 3_000_001), (1024, 2_500_000), (48, 2_000_000), (40, 2_000_000), (97, 1_500_000), (64, 2_000_000), (128, 2_200_000)):
         data = records(n, width, 0x5EC0 + width)
         for lv in ("default", "best", "fast"):
             agree(da, ctx, data, *LV[lv])
