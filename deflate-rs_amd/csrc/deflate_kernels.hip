@@ -1556,6 +1556,28 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
 }
 
+// Small inputs (at most M3_BOTH_UNITS workgroups): one launch whose workgroups take the table their epoch is marked for --
+// the second launch's 5 us are 2 % of a 167 KB file's time.  (Not for large inputs: the two bodies in one kernel cost the
+// plain one registers, + 2 % on text.)
+#ifndef MI355_M3_BOTH_UNITS
+#define MI355_M3_BOTH_UNITS 256
+#endif
+constexpr uint32_t M3_BOTH_UNITS = MI355_M3_BOTH_UNITS;
+template <bool HAS_Q>
+__global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3_both(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
+                                                const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
+                                                uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
+                                                SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
+                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
+    __shared__ __attribute__((aligned(256))) uint4 s_T[M3_TABLE_U4];
+    __shared__ uint32_t s_next;
+    const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
+    if (MI355_SWZ_BANKS && __builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2]))
+        m3_epoch<HAS_Q, true>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+    else
+        m3_epoch<HAS_Q, false>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_rle: rle.rs:13-18 get_match_length_rle for every position: R[p] = run of data[p-1]
 // starting at p, capped at 258 and at the end of input.
@@ -2336,6 +2358,11 @@ __global__ __launch_bounds__(1024) void k_scan_b(uint32_t K, const uint32_t* __r
         }
     }
 }
+// The call's scalars for the host, written by the device into page-locked host memory: the runtime's copy of 240 bytes was a
+// 3.5 us kernel of its own behind 5.8 us of idle queue.
+__global__ __launch_bounds__(64) void k_state_out(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t words) {
+    for (uint32_t i = threadIdx.x; i < words; i += 64) dst[i] = src[i];
+}
 // K == 0: no tokens
 __global__ void k_scan_zero(DevScalars* sc) {
     if (threadIdx.x || blockIdx.x) return;
@@ -2363,7 +2390,7 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t K, const uint32_t* __r
 // base[k] <= t -- by a search that looks at 64 places per round (three rounds for 2^18 segments: a thread's binary
 // search was seventeen memory latencies in a row), the covers of the segment's tokens before t summed across the lanes.
 __device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, const uint32_t* E0,
-                                const uint32_t* tokbuf, uint32_t lane) {
+                                const uint32_t* tokbuf, uint32_t lane, uint32_t* seg = nullptr) {
     uint32_t lo = 0, hi = K;
     while (hi - lo > 1) {
         const uint32_t span1 = hi - lo - 1;
@@ -2374,6 +2401,7 @@ __device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, co
         lo = nlo;
         hi = nhi;
     }
+    if (seg) *seg = lo;
     const uint32_t m = t - base[lo];
     const uint32_t* tk = tokbuf + (uint64_t)lo * SEG;
     uint32_t cov = 0;
@@ -2500,6 +2528,100 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
         tab.sync[b] = (j + 1 == nbi && (i + 1 < sg.m || sync_final)) ? 1u : 0u;
         bstart[b] = bs;
         q13[b] = flag;
+    }
+}
+
+// k_small_tail: k_scan_a + k_scan_b + k_block_bounds of a one-shot call (one segment end) of at most 1024 token segments --
+// 1 MiB -- in ONE workgroup: each of the three was a 4.5 us kernel of one to four workgroups.  k_compact follows it (the
+// tokens made dense by this one workgroup took 8 us of a 167 KB file's), so the last token of a full block is read from its
+// segment's slot, not from the dense array.
+#ifndef MI355_SMALL_TAIL
+#define MI355_SMALL_TAIL 1
+#endif
+constexpr uint32_t SMALL_TAIL_SEGS = 1024;
+__global__ __launch_bounds__(1024) void k_small_tail(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode, SegEnds sg, uint32_t sync_final,
+                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ E0,
+                                                     const uint32_t* __restrict__ Xs, uint32_t* __restrict__ spec_bad,
+                                                     uint32_t* __restrict__ base, const uint32_t* __restrict__ tokbuf,
+                                                     DevScalars* sc, uint32_t* __restrict__ tend,
+                                                     uint32_t* __restrict__ pb, uint32_t* __restrict__ bstart,
+                                                     uint32_t* __restrict__ q13, BlockTab tab) {
+    __shared__ uint32_t wtot[16], wbad[16], s_base[SMALL_TAIL_SEGS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- the chain of entries and exits (k_scan_a), the scan of the token counts (k_scan_b) ----
+    uint32_t nbad = 0;
+    if (Xs) {
+        const bool off = tid > 0 && tid < K && E0[tid] != Xs[tid - 1];
+        nbad = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off));
+    }
+    const uint32_t v = tid < K ? cnt[tid] : 0;
+    const uint32_t x = wave_incl_scan(v, lane);
+    if (lane == 63) wtot[wv] = x;
+    if (lane == 0) wbad[wv] = nbad;
+    __syncthreads();
+    const uint32_t T0 = sc->Tcum[0];
+    uint32_t add = T0, all = 0, bad = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        add += k < wv ? wtot[k] : 0;
+        all += wtot[k];
+        bad += wbad[k];
+    }
+    const uint32_t mine = add + x - v;
+    s_base[tid] = mine;
+    if (tid < K) base[tid] = mine;
+    const uint32_t T = T0 + all, nb = T / (uint32_t)MAX_BUFFER_LENGTH + 1u;
+    if (tid == 0) {
+        if (bad) atomicAdd(spec_bad, bad);
+        sc->T = T;
+        sc->nb = nb;
+        sc->Tcum[1] = T;
+        sc->nbcum[1] = nb;
+        tend[0] = T;
+        pb[0] = 0;
+        pb[1] = nb;
+    }
+    __syncthreads();
+    // ---- k_block_bounds: a wave per block, and one for the end behind the last (sc->nbcum[0] is 0: one piece) ----
+    for (uint32_t b = wv; b <= nb && b <= nb_max; b += 16) {
+        if (b == nb) {
+            if (lane == 0) bstart[b] = n;
+            continue;
+        }
+        const uint32_t t0 = b * (uint32_t)MAX_BUFFER_LENGTH;
+        const uint32_t left = T - t0;
+        const uint32_t nt = left < MAX_BUFFER_LENGTH ? left : (uint32_t)MAX_BUFFER_LENGTH;
+        const uint32_t bs = nt ? token_start(t0, K, s_base, E0, tokbuf, lane) : sg.ends[0];  // (the bases from LDS: this workgroup wrote them)
+        uint32_t flag = 0;
+        if (nt == MAX_BUFFER_LENGTH) {  // a full block: look at its last token
+            const uint32_t t1 = t0 + MAX_BUFFER_LENGTH - 1;
+            uint32_t seg = 0;
+            const uint32_t tp = token_start(t1, K, s_base, E0, tokbuf, lane, &seg);
+            const uint32_t tk = tokbuf[(uint64_t)seg * SEG + (t1 - s_base[seg])];
+            if (tp < WINDOW_SIZE && lane == 0) {  // (Q1, lz77.rs:628-638)
+                sc->b0_full = 1;
+                sc->b0_last_tok = tk;
+                sc->b0_last_pos = tp;
+            }
+            if (tk >> 16) {  // lz77.rs:679-695
+                const uint64_t lp = (mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
+                const uint64_t wdx = lp / WINDOW_SIZE;
+                const uint64_t wend = (wdx + 1) * (uint64_t)WINDOW_SIZE;
+                const uint64_t mend = (uint64_t)tp + tok_cover(tk);
+                if (wdx >= 1 && mend > wend) {
+                    uint64_t buf_end = wdx * (uint64_t)WINDOW_SIZE + 65794;
+                    const uint64_t have = sg.ends[0];
+                    if (buf_end > have) buf_end = have;
+                    flag = (mend + WINDOW_SIZE > buf_end) ? 2u : 1u;
+                }
+            }
+        }
+        if (lane == 0) {
+            tab.t0[b] = t0;
+            tab.nt[b] = nt;
+            tab.sync[b] = (b + 1 == nb && sync_final) ? 1u : 0u;
+            bstart[b] = bs;
+            q13[b] = flag;
+        }
     }
 }
 

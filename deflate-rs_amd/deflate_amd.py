@@ -243,7 +243,7 @@ class Context:
         raise DeflateError(rc, load().mi355_deflate_last_error(self._h).decode())
 
     CFG_RANGE_BYTES, CFG_LONG_FROM, CFG_SORT_RANKS, CFG_HOST_STREAMING, CFG_MULTI_STITCH, CFG_STEPS_IN_EMIT = 1, 2, 3, 4, 5, 6
-    CFG_HOST_BOUNCE, CFG_HOST_THREADS = 7, 8
+    CFG_HOST_BOUNCE, CFG_HOST_THREADS, CFG_STAGE_CLOCKS = 7, 8, 9
     HOST_PATH_PIECES, HOST_PATH_IN_THREADS, HOST_PATH_OUT_THREADS = 1, 2, 4
 
     def config(self, key, value):

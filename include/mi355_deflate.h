@@ -147,7 +147,11 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *                          by the kernel that writes the tokens, from the match table, where that is possible (the lazy and
  *                          greedy levels without a quarter-budget table, input without flush points); 0 = always by a kernel
  *                          of their own that leaves them in device memory (what the exact path search, `Best` and flushed
- *                          streams use anyway).  Same bytes either way: a testing and measuring aid. */
+ *                          streams use anyway).  Same bytes either way: a testing and measuring aid.
+ *   MI355_CFG_STAGE_CLOCKS  the per-stage clocks in mi355_deflate_info -- stage_ms, match_ms --: 2 (default) = for calls of 32 MiB or
+ *                          more, 1 = for every call, 0 = never.  They are events between the kernels of a call, each 5.7 us of
+ *                          idle queue -- a tenth of a 167 KB call; without them stage_ms and match_ms read 0 and total_ms is the
+ *                          time from the call's first kernel to its last. */
 #define MI355_CFG_RANGE_BYTES 1
 #define MI355_CFG_LONG_FROM 2
 #define MI355_CFG_SORT_RANKS 3
@@ -156,6 +160,7 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
 #define MI355_CFG_STEPS_IN_EMIT 6
 #define MI355_CFG_HOST_BOUNCE 7
 #define MI355_CFG_HOST_THREADS 8
+#define MI355_CFG_STAGE_CLOCKS 9
 int mi355_deflate_ctx_config(mi355_deflate_ctx* ctx, int key, uint64_t value);
 
 /* deflate_bytes_conf / deflate_bytes_zlib_conf (src/lib.rs:137-147, 182-198): host buffers

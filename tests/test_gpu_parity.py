@@ -165,6 +165,61 @@ def test_custom_options(da, ctx):
         agree(da, ctx, data, c, l, m)
 
 
+def test_small_one_shot_calls_between_parse_and_histograms(da, ctx):
+    """One-shot calls of at most 1024 token segments (1 MiB) run the check of the segment chain, the scan of the token
+    counts, the dense token array and the block table as ONE workgroup (k_small_tail; the tokens are made dense in it up
+    to 256 segments): sizes on both sides of its two limits, data with many full blocks (their last tokens are read for the
+    Q1 / Q13 questions), data whose speculative parse fails (the exact parse takes the same kernel), every level."""
+    seg = 1024
+    text = datagen.text_like(1100 * seg, 41)
+    noise = datagen.rng_bytes(1100 * seg, 42)
+    for n in (seg - 1, seg, seg + 1, 255 * seg + 7, 256 * seg, 256 * seg + 1, 700 * seg + 3, 1024 * seg - 1, 1024 * seg,
+              1024 * seg + 1):
+        for level in LV:
+            agree(da, ctx, text[:n], *LV[level])
+            agree(da, ctx, noise[:n], *LV[level])
+    # matches that cross block ends in the second and later windows (Q13), blocks that fill with a match
+    rep = datagen.rng_bytes(40000, 43)
+    for data in (rep * 20, (rep[:33000] + noise[:9000]) * 6, b"ab" * 300000, bytes(200 * seg),
+                 datagen.mixed(900 * seg, 44), datagen.rng_bytes(300, 45) * 800):
+        for level in LV:
+            agree(da, ctx, data, *LV[level])
+    # a sync flush behind everything that was written (the block table's sync marker), raw and zlib
+    import io
+    for n in (5000, 200 * seg + 5, 600 * seg):
+        for wrapper, cls in ((0, da.DeflateEncoder), (1, da.ZlibEncoder)):
+            _drive(lambda: cls(io.BytesIO(), da.CompressionOptions(*LV["default"]), ctx),
+                   lambda: ob.Stream(ob.make_opts(*LV["default"], wrapper)), text[:n], [], flush_at_end=True)
+
+
+def test_stage_clocks_are_optional(da):
+    """mi355_deflate_info's per-stage clocks are events between the kernels of a call (5.7 us of idle queue each): calls below
+    32 MiB run without them unless MI355_CFG_STAGE_CLOCKS asks -- stage_ms and match_ms then read 0, total_ms is the host's
+    clock -- and the bytes are the same either way."""
+    c = da.Context(0)
+    try:
+        data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
+        ref = ob.encode(data, level=ob.DEFAULT)
+        seen = {}
+        for mode in (2, 0, 1, 2):
+            c.config(da.Context.CFG_STAGE_CLOCKS, mode)
+            assert c.encode(data, da.Compression.Default) == ref
+            i = c.info()
+            assert i["total_ms"] > 0
+            seen[mode] = (i["match_ms"], sum(i["stage_ms"].values()))
+        assert seen[0] == (0.0, 0.0) and seen[2] == (0.0, 0.0)
+        assert seen[1][0] > 0 and seen[1][1] > 0
+        big = datagen.text_like(40 << 20, 77)  # (from 32 MiB on the default has them)
+        c.config(da.Context.CFG_STAGE_CLOCKS, 2)
+        out = _encode_resident(da, c, big, da.Compression.Fast)  # (a host call of this size is worked on in pieces, which have clocks of their own)
+        assert c.info()["match_ms"] > 0
+        assert inflate_raw(out) == big
+        with pytest.raises(da.DeflateError):
+            c.config(da.Context.CFG_STAGE_CLOCKS, 3)
+    finally:
+        c.close()
+
+
 def test_periodic_and_runs(da, ctx):
     for data in (b"ab" * 70000, b"abc" * 50000, bytes(100) + b"x" + bytes(200000),
                  datagen.rng_bytes(300, 5) * 500, datagen.rng_bytes(32768, 6) * 4,

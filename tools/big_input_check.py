@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 import sys, zlib, time
 sys.path.insert(0,"deflate-rs_amd"); sys.path.insert(0,"tests")
 import torch, datagen, deflate_amd as da

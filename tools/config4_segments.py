@@ -2,6 +2,7 @@
 encoded on its own at Compression::Best: match-stage ms per MB says which kind of data the walk is slow on.
     python tools/config4_segments.py > profiles/rNN_config4_segments.txt"""
 import os, sys
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("deflate-rs_amd", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))

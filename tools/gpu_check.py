@@ -2,6 +2,7 @@
 oracle with block-level localisation.  Not part of the product."""
 import glob
 import os
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 import sys
 import time
 

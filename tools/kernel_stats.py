@@ -2,6 +2,7 @@
 (`make -C deflate-rs_amd stats` -> variants/libstats.so, -DMI355_MATCH_STATS).
 usage: kernel_stats.py [match|sort] [bytes] [default|best|fast] [text|silesia|zeros]"""
 import ctypes as C, os, subprocess, sys
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.environ.get("MI355_STATS_LIB", os.path.join(ROOT, "deflate-rs_amd", "variants", "libstats.so"))
 if not os.path.exists(LIB):

@@ -1,5 +1,6 @@
 """Development aid (GPU box): stage times of resident encodes over a ladder of sizes (text, Default)."""
 import os, sys, time, statistics
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

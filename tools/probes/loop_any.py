@@ -1,6 +1,7 @@
 """Development aid (GPU box): N device-resident encodes of a chosen input with the library MI355_DEFLATE_LIB names, nothing checked
 -- for rocprofv3 over build variants.   loop_any.py <records96|records40|records256|text|dbrows|rows:WIDTH> <default|best|fast> [reps] [MB]"""
 import os, sys
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT="/root/repo"
 sys.path.insert(0, os.path.join(ROOT, "deflate-rs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, datagen, deflate_amd as da
