@@ -995,7 +995,7 @@ __global__ __launch_bounds__(1024) void k_sort(const uint8_t* __restrict__ in, u
 // they took the walk's scalar registers, the instrumented kernel spilled 60 bytes a lane and its clock shares were those of
 // another kernel.  32 bits hold a wave's totals, and differences survive the wrap.)
 #define M2_CNT(i, v) \
-    if (((MI355_MATCH_STATS) & 2) || (i) == 0) m2c[i] += (uint32_t)(v);
+    if (((MI355_MATCH_STATS) & 2) || (i) == 0 || (i) == 4) m2c[i] += (uint32_t)(v);
 #define M2_T0 uint32_t m2t = ((MI355_MATCH_STATS) & 1) ? (uint32_t)__builtin_readcyclecounter() : 0u;
 #define M2_T(i)                                                      \
     if ((MI355_MATCH_STATS) & 1) {                                   \
@@ -1284,6 +1284,10 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
                                          HashOverride ov, uint32_t split, uint32_t* __restrict__ Ms, uint32_t* __restrict__ Mqs,
                                          uint32_t* __restrict__ sort_bad) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+#ifdef MI355_MATCH_STATS
+    uint32_t m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    M2_T0
     const uint64_t E = (uint64_t)e * WINDOW_SIZE;
     const uint64_t wbase = e ? E - WINDOW_SIZE : 0;
     const uint32_t wbytes = (uint32_t)(E - wbase) + WINDOW_SIZE + 258 + 14;
@@ -1340,10 +1344,7 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
     const uint16_t* Bown = Bg + (size_t)e * BSTRIDE;
     const uint16_t* Bprev = Bown - BSTRIDE;
     TileLimit lim{sg, wbase, sg.m == 1 ? (uint32_t)(sg.ends[0] - wbase) : 0u};
-#ifdef MI355_MATCH_STATS
-    uint32_t m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    M2_T0
+    M2_T(10)  // (the window staged, the barrier)
     uint32_t unordered = 0;
     // set a fibre up for batch b (all lanes call it: the lane masks it sets must be ballots of the whole wave)
     // (before0: the entry in front of the batch's first one, for the order check below)
@@ -1486,6 +1487,7 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
     else
         walk_all(std::false_type{});
     if (__builtin_amdgcn_ballot_w64(unordered != 0) != 0 && lane == 0) atomicOr(sort_bad, 1u);
+    M2_T(11)  // (a wave's last results, and the wait for nothing: the walk's loop ended at its last M2_T)
     if (Ms) {
         // The results went out in the order of S_e -- a batch's 64 results are 256 consecutive bytes; stored by position
         // they were 64 stores into 64 lines, which left the L2 as partial lines over and over (WRITE_SIZE 4.6 GB for
@@ -1509,6 +1511,8 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
             }
         }
     }
+    M2_T(14)  // (the results turned round: whole epochs only)
+    M2_CNT(4, 1)  // waves
 #ifdef MI355_MATCH_STATS
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_mstats[i], (unsigned long long)m2c[i]);
@@ -2729,9 +2733,45 @@ struct HdrLds {
 };
 
 // Moffat-Katajainen phase 1 on one lane: val[0..n) ascending; afterwards val[t] = parent of internal node t
-// for t < n - 2 (length_encode.rs:218-247).  rv / lv = the weights at the heads of the internal-node and the
-// leaf queue; an internal node is made in every round, so its queue is never empty when a round begins.
+// for t < n - 2 (length_encode.rs:218-247).  The two items a round pairs are the two smallest of the next two of the
+// internal-node queue (r0, r1) and the next two leaves (l0, l1): all four are fetched before the round looks at any of them
+// and the round itself has no branch -- a queue that has run out (no leaf left; no internal node made yet that is not taken)
+// reads as the largest value, which is what the reference's conditions `leaf >= n ||` and `root < next &&` come to: ties go
+// to the leaf, an internal node is made in every round, so the queue is never empty when a round begins.  (Before: the next
+// weight of whichever queue a pick took from was read when the pick was made -- two dependent LDS reads and two branches a
+// round, 474 cycles a round on the one lane, half of k_block_header on a block of text.)
+#ifndef MI355_MK_WINDOW
+#define MI355_MK_WINDOW 1
+#endif
 __device__ void mk_phase1(uint32_t* val, uint32_t n) {
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+#if MI355_MK_WINDOW
+    uint32_t root = 0, leaf = 2;
+    uint32_t r0 = val[0] + val[1], r1 = INF;
+    val[0] = r0;
+    uint32_t l0 = leaf < n ? val[leaf] : INF, l1 = leaf + 1 < n ? val[leaf + 1] : INF;
+    for (uint32_t next = 1; next + 1 < n; next++) {
+        const bool t1 = r0 < l0;  // first pick: the internal node unless the leaf is at most as heavy
+        const uint32_t a = t1 ? r0 : l0;
+        const uint32_t rr = t1 ? r1 : r0, ll = t1 ? l0 : l1;
+        const bool t2 = rr < ll;  // second pick
+        const uint32_t v = a + (t2 ? rr : ll);
+        const uint32_t cr = (t1 ? 1u : 0u) + (t2 ? 1u : 0u);
+        // the nodes taken get their parent (they are root, root + 1: below next)
+        if (cr >= 1) val[root] = next;
+        if (cr == 2) val[root + 1] = next;
+        val[next] = v;
+        root += cr;
+        leaf += 2 - cr;
+        // the heads of both queues for the next round (node `next` is in the queue now)
+        r0 = val[root <= next ? root : next];  // (root <= next always: the node just made is there)
+        const uint32_t r1v = val[root + 1 <= next ? root + 1 : next];
+        const uint32_t l0v = val[leaf < n ? leaf : n - 1], l1v = val[leaf + 1 < n ? leaf + 1 : n - 1];
+        r1 = root + 1 <= next ? r1v : INF;
+        l0 = leaf < n ? l0v : INF;
+        l1 = leaf + 1 < n ? l1v : INF;
+    }
+#else
     uint32_t root = 0, leaf = 2;
     uint32_t rv = val[0] + val[1];
     val[0] = rv;
@@ -2761,13 +2801,14 @@ __device__ void mk_phase1(uint32_t* val, uint32_t n) {
         val[next] = v;
         if (root == next) rv = v;
     }
+#endif
 }
 
 // One code, built by ONE wave (the two waves of the workgroup build the literal/length and the distance
 // code side by side): the lanes hand data to each other through the wave's scratch, so wave_lds_fence
 // stands where a workgroup would need a barrier.
 #ifdef MI355_HDR_TIMERS
-#define HT(i) { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) ht[i] += t_ - ht0; ht0 = __builtin_readcyclecounter(); }
+#define HT(i) { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x == 0) ht[i] += t_ - ht0; ht0 = __builtin_readcyclecounter(); }  // (wave 0 of block 0: the literal/length code's wave -- the kernel's critical path)
 #define HT_DECL unsigned long long ht0 = __builtin_readcyclecounter();
 __device__ unsigned long long ht[16];
 #else
@@ -2776,7 +2817,8 @@ __device__ unsigned long long ht[16];
 #endif
 template <class LenArr>
 __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
-                          LenArr& lengths, uint32_t lane) {
+                          LenArr& lengths, uint32_t lane, uint32_t htb = 0) {
+    (void)htb;
     HT_DECL
     for (uint32_t i = lane; i < n_total; i += 64) lengths[i] = 0;
     uint32_t m = 0;  // gather_nodes
@@ -2814,10 +2856,10 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
             }
     }
     wave_lds_fence();
-    HT(0)
+    HT(0 + htb)
     if (lane == 0) mk_phase1(s.val, m);
     wave_lds_fence();
-    HT(1)
+    HT(1 + htb)
     // internal nodes 0 .. m-2, the root is m-2: depth = number of parent hops to the root
     const uint32_t rootn = m - 2;
     for (uint32_t t = lane; t + 1 < m; t += 64) {
@@ -2846,7 +2888,7 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
     }
     for (uint32_t t = lane; t + 1 < m; t += 64) atomicAdd(&s.icnt[s.pj[t] >> 16], 1u);
     wave_lds_fence();
-    HT(2)
+    HT(2 + htb)
     if (lane == 0) {
         // :253-278 level by level: of the `available` slots of a depth the internal nodes take theirs, the
         // leaves the rest
@@ -2860,7 +2902,7 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
         limit_code_lengths(s.num, max_len);
     }
     wave_lds_fence();
-    HT(3)
+    HT(3 + htb)
     for (uint32_t idx = lane; idx < m; idx += 64) {  // :402-408: the idx-th leaf from the end
         uint32_t acc = 0, len = 0;
         for (uint32_t i = 1; i <= max_len; i++) {
@@ -2870,7 +2912,7 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
         lengths[s.sym[m - 1 - idx]] = (uint8_t)len;
     }
     wave_lds_fence();
-    HT(4)
+    HT(4 + htb)
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -2961,7 +3003,7 @@ __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, cons
     if (wv == 0) { HT(7) }
     BlockHeader* h = hdr + b;
     if (wv == 0) {
-        wave_huff(s.w[0], s.clf, 19, 19, 7, s.cl_len, lane);
+        wave_huff(s.w[0], s.clf, 19, 19, 7, s.cl_len, lane, 9);
         if (lane == 0) s.used = count_used_hclens(s.cl_len);
     }
     __syncthreads();
@@ -3012,8 +3054,8 @@ __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, cons
     HT(8)
 #ifdef MI355_HDR_TIMERS
     if (lane == 0 && b == 0) {
-        printf("hdr timers (cycles): load %llu | huff: gather+sort %llu phase1 %llu depths %llu levels+limit %llu handout %llu | (whole first phase %llu) rle %llu rest %llu\n",
-               ht[5], ht[0], ht[1], ht[2], ht[3], ht[4], ht[6], ht[7], ht[8]);
+        printf("hdr timers (cycles, the literal/length wave of block 0): load %llu | ll code: gather+sort %llu phase1 %llu depths %llu levels+limit %llu handout %llu (the whole, with the wait for the distance wave and the chain: %llu) | rle + count %llu | cl code: gather+sort %llu phase1 %llu depths %llu levels+limit %llu handout %llu (with the costs: %llu)\n",
+               ht[5], ht[0], ht[1], ht[2], ht[3], ht[4], ht[6], ht[7], ht[9], ht[10], ht[11], ht[12], ht[13], ht[8]);
         for (int i = 0; i < 16; i++) ht[i] = 0;
     }
 #endif

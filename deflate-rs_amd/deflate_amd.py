@@ -250,7 +250,7 @@ class Context:
         """mi355_deflate_ctx_config: range size / long-input threshold / where the sort takes its ranks from"""
         rc = load().mi355_deflate_ctx_config(self._h, int(key), int(value))
         if rc != OK:
-            raise DeflateError(rc, self.last_error())
+            self._err(rc)
 
     def reserve(self, in_len, host_api=False):
         """mi355_deflate_ctx_reserve: allocate for inputs of up to in_len bytes now"""
