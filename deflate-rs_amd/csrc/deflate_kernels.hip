@@ -2025,37 +2025,28 @@ struct SpecFix {
     uint32_t* badmap;        // the same as a bit per segment
     const uint32_t* n;       // how many
 };
-// (STEPS: the wave works the restart steps out itself, from M -- adv is not read; else they come from k_adv / k_rle through adv)
+// (the rows of a wave: STEP_CHUNKS * 256 + 8 entries where the steps are worked out here -- STEPS: they go through 256 positions
+// at a time and look eight entries beyond a position --, else the positions the wave holds)
 template <int MODE, bool STEPS>
-__global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
-                                              const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
-                                              ParseCfg cfg, const uint16_t* __restrict__ adv,
-                                              uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
-                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
-                                              uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0, uint32_t seg0) {
-    constexpr bool SPEC = MODE == 1;
-    constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
-    // (rows of STEP_CHUNKS * 256 + 8 entries: the steps worked out here -- STEPS -- go through 256 positions at a time
-    // and look eight entries beyond a position)
-    constexpr uint32_t ROW = STEPS ? STEP_CHUNKS * 256 + 8 : REG;
+struct EmitRows {
+    static constexpr bool SPEC = MODE == 1;
+    static constexpr uint32_t REG = SEG + (SPEC ? SPEC_W : 0u);  // positions a wave holds: its segment and the run-up in front of it
+    static constexpr uint32_t ROW = STEPS ? STEP_CHUNKS * 256 + 8 : REG;
     static_assert(REG + 12 <= STEP_CHUNKS * 256 && ROW % 4 == 0, "the chunks cover the region and what a step looks at behind it");
-    __shared__ __attribute__((aligned(8))) uint16_t s_adv[4][ROW];
-    __shared__ __attribute__((aligned(8))) uint16_t s_pp[4][ROW];
-    __shared__ uint32_t s_np[4], s_exit[4];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
-    uint32_t given = 0;  // MODE 2: the entry the segment is parsed from
-    if (MODE == 2) {
-        const uint32_t nf = *fix.n;
-        if (nf > FIX_MAX || k >= nf) return;
-        // (the exit of the segment before it as k_spec_check saw it -- not Xs[k - 1] as it is now, which a wave that repairs the
-        // segments before this one may be rewriting: what a repair is based on must not depend on which wave runs first)
-        given = fix.list[2 * k + 1];
-        k = fix.list[2 * k];
-    }
-    if (k >= K) return;  // whole wave; no workgroup barrier is used below
-    uint16_t* A = s_adv[wv];
-    uint16_t* P = s_pp[wv];
+};
+// One wave, one segment (MODE 2: and the segments behind it while the repair goes on).  A, P: the wave's two rows in LDS;
+// np_w, exit_w: a word each.  No workgroup barrier inside.
+template <int MODE, bool STEPS>
+__device__ __forceinline__ void emit_wave(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
+                                          const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
+                                          const ParseCfg& cfg, const uint16_t* __restrict__ adv,
+                                          uint32_t* E0, uint32_t* __restrict__ tokbuf,
+                                          uint32_t* cnt, uint32_t pos0, uint32_t n_total, const SegEnds& sg,
+                                          uint32_t* Xs, const uint32_t* badmap, uint32_t runup0,
+                                          uint16_t* A, uint16_t* P, uint32_t* np_w, uint32_t* exit_w, uint64_t k, uint32_t given,
+                                          uint32_t lane) {
+    constexpr bool SPEC = MODE == 1;
+    constexpr uint32_t REG = EmitRows<MODE, STEPS>::REG;
     for (uint32_t hop = 0;; hop++) {
     // (runup0: the first segment has data in front of it as well -- a range of a sharded or long encode with its history --
     // and finds its entry like the others; without it the first segment starts at the stream's true entry, position 0)
@@ -2177,11 +2168,11 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
             P[np++] = (uint16_t)at;
         }
         if (MODE != 0) Xs[k] = (uint32_t)(a + j);  // where the path leaves the segment
-        s_exit[wv] = (uint32_t)(a + j);
-        s_np[wv] = np;
+        *exit_w = (uint32_t)(a + j);
+        *np_w = np;
     }
     wave_lds_fence();
-    const uint32_t np = s_np[wv];
+    const uint32_t np = *np_w;
     uint32_t* out = tokbuf + a0;
     // (32-bit positions relative to the first byte the wave holds: tables, input and the end of the data)
     const uint64_t sbase = (uint64_t)pos0 + a;
@@ -2251,14 +2242,42 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
     if (lane == 0) cnt[k] = running;
     if (MODE != 2) break;
     // the repair goes on while the exit of the segment just parsed is not the entry the next one was parsed from
-    const uint32_t x = s_exit[wv];
+    const uint32_t x = *exit_w;
     wave_lds_fence();
     k++;
     if (k >= K || hop + 1 >= FIX_HOPS) break;
-    if ((fix.badmap[k >> 5] >> (k & 31)) & 1u) break;  // (listed: another wave's)
+    if ((badmap[k >> 5] >> (k & 31)) & 1u) break;  // (listed: another wave's)
     if (E0[k] == x) break;                             // the paths have met
     given = x;
     }
+}
+
+// (STEPS: the wave works the restart steps out itself, from M -- adv is not read; else they come from k_adv / k_rle through adv)
+template <int MODE, bool STEPS>
+__global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
+                                              const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq,
+                                              ParseCfg cfg, const uint16_t* __restrict__ adv,
+                                              uint32_t* __restrict__ E0, uint32_t* __restrict__ tokbuf,
+                                              uint32_t* __restrict__ cnt, uint32_t pos0, uint32_t n_total, SegEnds sg,
+                                              uint32_t* __restrict__ Xs, SpecFix fix, uint32_t runup0, uint32_t seg0) {
+    constexpr uint32_t ROW = EmitRows<MODE, STEPS>::ROW;
+    __shared__ __attribute__((aligned(8))) uint16_t s_adv[4][ROW];
+    __shared__ __attribute__((aligned(8))) uint16_t s_pp[4][ROW];
+    __shared__ uint32_t s_np[4], s_exit[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t k = (uint64_t)blockIdx.x * 4 + wv + seg0;  // (seg0: a launch may cover a range of segments)
+    uint32_t given = 0;  // MODE 2: the entry the segment is parsed from
+    if (MODE == 2) {
+        const uint32_t nf = *fix.n;
+        if (nf > FIX_MAX || k >= nf) return;
+        // (the exit of the segment before it as k_spec_check saw it -- not Xs[k - 1] as it is now, which a wave that repairs the
+        // segments before this one may be rewriting: what a repair is based on must not depend on which wave runs first)
+        given = fix.list[2 * k + 1];
+        k = fix.list[2 * k];
+    }
+    if (k >= K) return;  // whole wave; no workgroup barrier is used below
+    emit_wave<MODE, STEPS>(in, n, K, M, Mq, cfg, adv, E0, tokbuf, cnt, pos0, n_total, sg, Xs, fix.badmap, runup0, s_adv[wv], s_pp[wv],
+                           &s_np[wv], &s_exit[wv], k, given, lane);
 }
 
 // k_spec_check: after the speculative k_emit, which segments were entered somewhere else than the segment before them was
@@ -2535,44 +2554,95 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
     }
 }
 
-// k_small_tail: k_scan_a + k_scan_b + k_block_bounds of a one-shot call (one segment end) of at most 1024 token segments --
-// 1 MiB -- in ONE workgroup: each of the three was a 4.5 us kernel of one to four workgroups.  k_compact follows it (the
-// tokens made dense by this one workgroup took 8 us of a 167 KB file's), so the last token of a full block is read from its
-// segment's slot, not from the dense array.
+// k_small_fix: what lies between the speculative parse and the dense tokens of a one-shot call (one segment end) of at most
+// 1024 token segments -- 1 MiB -- in ONE workgroup: k_spec_check, the repair (k_emit<2>), k_scan_a, k_scan_b and k_block_bounds
+// were five launches of 4.5 us each, of one to four workgroups, with (on anything but periodic data) nothing to repair.
+//   1  which segments were entered somewhere else than the one before them was left: the bits and the list of k_spec_check;
+//   2  a wave per listed segment parses it again from where the segment before it was left (emit_wave<2>, as k_emit<2>);
+//   3  the chain of entries and exits once more (what is still off fails the call's speculation: spec_bad), the scan of
+//      the token counts, the block table.  The last token of a full block is read from its segment's slot: the dense
+//      array is made by k_compact, behind this kernel.
+// (Xs == nullptr: the exact parse -- entries from the table tree -- has nothing to check or repair: step 3 only.)
 #ifndef MI355_SMALL_TAIL
 #define MI355_SMALL_TAIL 1
 #endif
-constexpr uint32_t SMALL_TAIL_SEGS = 1024;
-__global__ __launch_bounds__(1024) void k_small_tail(uint32_t n, uint32_t K, uint32_t nb_max, uint32_t mode, SegEnds sg, uint32_t sync_final,
-                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ E0,
-                                                     const uint32_t* __restrict__ Xs, uint32_t* __restrict__ spec_bad,
-                                                     uint32_t* __restrict__ base, const uint32_t* __restrict__ tokbuf,
-                                                     DevScalars* sc, uint32_t* __restrict__ tend,
-                                                     uint32_t* __restrict__ pb, uint32_t* __restrict__ bstart,
-                                                     uint32_t* __restrict__ q13, BlockTab tab) {
-    __shared__ uint32_t wtot[16], wbad[16], s_base[SMALL_TAIL_SEGS];
+constexpr uint32_t SMALL_TAIL_SEGS = 1024, SMALL_FIX_T = 512;
+template <bool STEPS>
+__global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
+                                                           const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq, ParseCfg cfg,
+                                                           const uint16_t* __restrict__ adv, uint32_t* E0, uint32_t* __restrict__ tokbuf,
+                                                           uint32_t* cnt, SegEnds sg, uint32_t* Xs, uint32_t* badmap, uint32_t* list,
+                                                           uint32_t nb_max, uint32_t sync_final, uint32_t* __restrict__ spec_bad,
+                                                           uint32_t* __restrict__ base, DevScalars* sc, uint32_t* __restrict__ tend,
+                                                           uint32_t* __restrict__ pb, uint32_t* __restrict__ bstart,
+                                                           uint32_t* __restrict__ q13, BlockTab tab) {
+    constexpr uint32_t ROW = EmitRows<2, STEPS>::ROW, NW = SMALL_FIX_T / 64;
+    __shared__ __attribute__((aligned(8))) uint16_t s_adv[NW][ROW];
+    __shared__ __attribute__((aligned(8))) uint16_t s_pp[NW][ROW];
+    __shared__ uint32_t s_np[NW], s_exit[NW], wtot[NW], wbad[NW], s_nfix, s_base[SMALL_TAIL_SEGS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // ---- the chain of entries and exits (k_scan_a), the scan of the token counts (k_scan_b) ----
+    if (Xs) {
+        // ---- 1: the check (k_spec_check) ----
+        if (tid == 0) s_nfix = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < SMALL_TAIL_SEGS; i0 += SMALL_FIX_T) {
+            const uint32_t i = i0 + tid;
+            if ((i & ~63u) >= K) break;  // (whole waves)
+            const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
+            const uint64_t m = __builtin_amdgcn_ballot_w64(off);
+            if (lane == 0) {
+                badmap[i >> 5] = (uint32_t)m;
+                badmap[(i >> 5) + 1] = (uint32_t)(m >> 32);
+            }
+            if (m == 0) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&s_nfix, (uint32_t)__popcll(m));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (off && at + rank < FIX_MAX) {
+                list[2 * (at + rank)] = i;
+                list[2 * (at + rank) + 1] = Xs[i - 1];  // what the repair parses the segment from
+            }
+        }
+        __syncthreads();
+        const uint32_t nf = s_nfix;
+        if (tid == 0) sc->n_fix[0] = nf;
+        // ---- 2: the repair (k_emit<2>) ----
+        if (nf != 0 && nf <= FIX_MAX) {
+            for (uint32_t u = wv; u < nf; u += NW) {
+                const uint32_t k = list[2 * u], given = list[2 * u + 1];
+                if (k < K)
+                    emit_wave<2, STEPS>(in, n, K, M, Mq, cfg, adv, E0, tokbuf, cnt, 0u, n, sg, Xs, badmap, 0u, s_adv[wv], s_pp[wv], &s_np[wv],
+                                        &s_exit[wv], k, given, lane);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 3: the chain of entries and exits (k_scan_a), the scan of the token counts (k_scan_b): two segments a thread ----
+    const uint32_t i0 = 2 * tid, i1 = 2 * tid + 1;
     uint32_t nbad = 0;
     if (Xs) {
-        const bool off = tid > 0 && tid < K && E0[tid] != Xs[tid - 1];
-        nbad = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off));
+        const bool off0 = i0 > 0 && i0 < K && E0[i0] != Xs[i0 - 1], off1 = i1 < K && E0[i1] != Xs[i1 - 1];
+        nbad = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off0)) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off1));
     }
-    const uint32_t v = tid < K ? cnt[tid] : 0;
+    const uint32_t c0 = i0 < K ? cnt[i0] : 0u, c1 = i1 < K ? cnt[i1] : 0u;
+    const uint32_t v = c0 + c1;
     const uint32_t x = wave_incl_scan(v, lane);
     if (lane == 63) wtot[wv] = x;
     if (lane == 0) wbad[wv] = nbad;
     __syncthreads();
     const uint32_t T0 = sc->Tcum[0];
     uint32_t add = T0, all = 0, bad = 0;
-    for (uint32_t k = 0; k < 16; k++) {
+    for (uint32_t k = 0; k < NW; k++) {
         add += k < wv ? wtot[k] : 0;
         all += wtot[k];
         bad += wbad[k];
     }
     const uint32_t mine = add + x - v;
-    s_base[tid] = mine;
-    if (tid < K) base[tid] = mine;
+    s_base[i0] = mine;
+    s_base[i1] = mine + c0;
+    if (i0 < K) base[i0] = mine;
+    if (i1 < K) base[i1] = mine + c0;
     const uint32_t T = T0 + all, nb = T / (uint32_t)MAX_BUFFER_LENGTH + 1u;
     if (tid == 0) {
         if (bad) atomicAdd(spec_bad, bad);
@@ -2586,7 +2656,7 @@ __global__ __launch_bounds__(1024) void k_small_tail(uint32_t n, uint32_t K, uin
     }
     __syncthreads();
     // ---- k_block_bounds: a wave per block, and one for the end behind the last (sc->nbcum[0] is 0: one piece) ----
-    for (uint32_t b = wv; b <= nb && b <= nb_max; b += 16) {
+    for (uint32_t b = wv; b <= nb && b <= nb_max; b += NW) {
         if (b == nb) {
             if (lane == 0) bstart[b] = n;
             continue;
@@ -2607,7 +2677,7 @@ __global__ __launch_bounds__(1024) void k_small_tail(uint32_t n, uint32_t K, uin
                 sc->b0_last_pos = tp;
             }
             if (tk >> 16) {  // lz77.rs:679-695
-                const uint64_t lp = (mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
+                const uint64_t lp = (cfg.mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
                 const uint64_t wdx = lp / WINDOW_SIZE;
                 const uint64_t wend = (wdx + 1) * (uint64_t)WINDOW_SIZE;
                 const uint64_t mend = (uint64_t)tp + tok_cover(tk);
@@ -2711,8 +2781,8 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
 // Local arrays with a dynamic index would live in scratch memory (one round trip to L2 per access): all
 // tables are in LDS.
 // ---------------------------------------------------------------------------------------------
-struct HuffScratch {     // what one wave needs to build one code
-    uint32_t key[288];   // freq << 9 | symbol of the used symbols
+struct __attribute__((aligned(16))) HuffScratch {  // what one wave needs to build one code
+    uint32_t key[292];   // freq << 9 | symbol of the used symbols (read four at a time: padded behind the last)
     uint32_t val[288];   // sorted frequencies -> Moffat-Katajainen working array
     uint32_t sym[288];   // symbol of every sorted leaf
     uint32_t pj[288];    // depth << 16 | ancestor of every internal node
@@ -2815,6 +2885,36 @@ __device__ unsigned long long ht[16];
 #define HT(i)
 #define HT_DECL
 #endif
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <uint32_t NQ>
+__device__ __forceinline__ void huff_rank_sort(HuffScratch& s, uint32_t m, uint32_t lane) {
+    uint32_t k[NQ], rank[NQ];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++) {
+        k[q] = lane + 64 * q < m ? s.key[lane + 64 * q] : 0u;
+        rank[q] = 0;
+    }
+    const uint4* kp = reinterpret_cast<const uint4*>(s.key);
+    uint4 kk = kp[0];
+    for (uint32_t j = 0; j < m; j += 4) {
+        const uint4 cur = kk;
+        kk = kp[(j >> 2) + 1];  // (at most one read behind the pad: inside the array)
+#pragma unroll
+        for (uint32_t q = 0; q < NQ; q++)
+            rank[q] += (cur.x < k[q] ? 1u : 0u) + (cur.y < k[q] ? 1u : 0u) + (cur.z < k[q] ? 1u : 0u) + (cur.w < k[q] ? 1u : 0u);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++)
+        if (lane + 64 * q < m) {
+            s.val[rank[q]] = k[q] >> 9;
+            s.sym[rank[q]] = k[q] & 511u;
+        }
+}
 template <class LenArr>
 __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uint32_t n_total, uint32_t max_len,
                           LenArr& lengths, uint32_t lane, uint32_t htb = 0) {
@@ -2836,24 +2936,16 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
         wave_lds_fence();
         return;
     }
-    {  // rank sort: a lane's (up to five) keys against every key
-        uint32_t k[5], rank[5];
-#pragma unroll
-        for (uint32_t q = 0; q < 5; q++) {
-            k[q] = lane + 64 * q < m ? s.key[lane + 64 * q] : 0u;
-            rank[q] = 0;
-        }
-        for (uint32_t j = 0; j < m; j++) {
-            const uint32_t kj = s.key[j];
-#pragma unroll
-            for (uint32_t q = 0; q < 5; q++) rank[q] += kj < k[q] ? 1u : 0u;
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 5; q++)
-            if (lane + 64 * q < m) {
-                s.val[rank[q]] = k[q] >> 9;
-                s.sym[rank[q]] = k[q] & 511u;
-            }
+    // rank sort: a lane's keys (one for every 64 symbols in use) against every key, four keys a read, the next four fetched
+    // before these are compared (one key a round and five registers whatever m is: 11 of the literal/length code's 80 kcycles)
+    if (lane < 4) s.key[m + lane] = 0xFFFFFFFFu;  // (behind the last: below no key)
+    wave_lds_fence();
+    switch ((m + 63) / 64) {
+    case 1: huff_rank_sort<1>(s, m, lane); break;
+    case 2: huff_rank_sort<2>(s, m, lane); break;
+    case 3: huff_rank_sort<3>(s, m, lane); break;
+    case 4: huff_rank_sort<4>(s, m, lane); break;
+    default: huff_rank_sort<5>(s, m, lane); break;
     }
     wave_lds_fence();
     HT(0 + htb)
@@ -2889,17 +2981,29 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
     for (uint32_t t = lane; t + 1 < m; t += 64) atomicAdd(&s.icnt[s.pj[t] >> 16], 1u);
     wave_lds_fence();
     HT(2 + htb)
-    if (lane == 0) {
-        // :253-278 level by level: of the `available` slots of a depth the internal nodes take theirs, the
-        // leaves the rest
-        uint32_t available = 1, depth = 0;
-        while (available > 0) {
-            const uint32_t used = depth + 1 < m ? s.icnt[depth] : 0u;
-            if (available > used) s.num[depth < 32 ? depth : 32] += available - used;
-            available = 2 * used;
-            depth++;
+    {
+        // :253-278 level by level: of the `available` slots of a depth -- one at the root, else two for every internal node a
+        // level up -- the internal nodes take theirs, the leaves the rest: a lane per depth (a level without internal nodes has
+        // none below it, so the loop's end needs no looking for)
+        for (uint32_t d = lane; d < m; d += 64) {
+            const uint32_t used = d + 1 < m ? s.icnt[d] : 0u;
+            const uint32_t available = d == 0 ? 1u : 2u * s.icnt[d - 1];  // (d - 1 + 1 < m)
+            const uint32_t leaves = available > used ? available - used : 0u;
+            if (d < 32)
+                s.num[d] = leaves;
+            else if (leaves)
+                atomicAdd(&s.num[32], leaves);
         }
-        limit_code_lengths(s.num, max_len);
+        wave_lds_fence();
+        // enforce_max_code_lengths :290-327 (stages.h limit_code_lengths): the Kraft sum by the wave; the loop that moves
+        // codes only where it is off (a depth beyond max_len, or more than a full tree after the fold)
+        const uint32_t nd = lane < 33 ? s.num[lane] : 0u;
+        const uint32_t above = wave_sum(lane > max_len ? nd : 0u);
+        const uint32_t mine = lane == max_len ? nd + above : nd;
+        const uint32_t total = wave_sum(lane >= 1 && lane <= max_len ? mine << (max_len - lane) : 0u);
+        if (above != 0 || total != (1u << max_len)) {
+            if (lane == 0) limit_code_lengths(s.num, max_len);
+        }
     }
     wave_lds_fence();
     HT(3 + htb)
@@ -2913,12 +3017,6 @@ __device__ void wave_huff(HuffScratch& s, const uint32_t* freqs, uint32_t n, uin
     }
     wave_lds_fence();
     HT(4 + htb)
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
 }
 
 __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, const uint32_t* __restrict__ ll_freq,
@@ -3068,11 +3166,10 @@ __global__ __launch_bounds__(128) void k_block_header(const DevScalars* sc, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void put_bits(uint32_t* out32, uint64_t bitpos, uint64_t bits, uint32_t nbits);
 
-__global__ __launch_bounds__(1024) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
-                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
-                                               BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
-                                               const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc) {
-    __shared__ uint32_t s_red[16], s_flag[3];
+__device__ __forceinline__ void plan_blocks(uint32_t* s_red, uint32_t* s_flag, DevScalars* sc, const BlockHeader* __restrict__ hdr,
+                                            const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
+                                            BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
+                                            const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc) {
     const uint32_t lane = threadIdx.x & 63;
     if (spec_failed(sc)) return;
     // (a piece: the blocks from sc->nbcum[pc.p] on, behind the bits planned so far; `fin` = the block that ends the stream)
@@ -3257,6 +3354,22 @@ __global__ __launch_bounds__(1024) void k_plan(DevScalars* sc, const BlockHeader
         sc->n_dynamic += n_dy;
         sc->q13_hits += hits;
         sc->ref_panic |= panic;
+    }
+}
+
+// (host_state: a small one-shot call's scalars are final with the plan -- k_pack writes none -- and leave for the host's
+// page-locked copy from here: the 240 bytes were a launch of their own)
+__global__ __launch_bounds__(1024) void k_plan(DevScalars* sc, const BlockHeader* __restrict__ hdr,
+                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
+                                               BlockPlan* __restrict__ plan, uint64_t bit_base, uint32_t compat,
+                                               const uint32_t* __restrict__ blk_sync, uint32_t* __restrict__ out32, Piece pc,
+                                               uint32_t* __restrict__ host_state) {
+    __shared__ uint32_t s_red[16], s_flag[3];
+    plan_blocks(s_red, s_flag, sc, hdr, bstart, q13, plan, bit_base, compat, blk_sync, out32, pc);
+    if (host_state) {
+        __syncthreads();  // (what one thread wrote into *sc above)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc);
+        if (threadIdx.x < sizeof(DevState) / 4) host_state[threadIdx.x] = src[threadIdx.x];
     }
 }
 
