@@ -3398,8 +3398,8 @@ constexpr uint32_t PACK_WORDS = 256 * 48 / 32 + 4;
 #ifndef MI355_PACK_THREADS
 #define MI355_PACK_THREADS 256
 #endif
-constexpr uint32_t PKT = MI355_PACK_THREADS;  // threads of a k_pack workgroup (a block of 31744 tokens in 31744 / (4 PKT) rounds)
-constexpr uint32_t PKW = PKT / 64;
+constexpr uint32_t PKT_LARGE = MI355_PACK_THREADS;  // threads of a k_pack workgroup (a part of a block, 7936 tokens, in 7936 / (4 PKT) rounds)
+constexpr uint32_t PKT_SMALL = 1024;                // ... of a call with fewer parts than compute units: a part's rounds are its time
 __device__ __forceinline__ void put_bits_lds(uint32_t* buf, uint32_t bitpos, uint64_t bits, uint32_t nbits) {
     if (nbits == 0) return;
     const uint32_t w = bitpos >> 5, sh = bitpos & 31;
@@ -3411,6 +3411,7 @@ __device__ __forceinline__ void put_bits_lds(uint32_t* buf, uint32_t bitpos, uin
     if (hi) atomicOr(buf + w + 2, hi);
 }
 
+template <uint32_t PKW>
 struct alignas(4) PackLds {
     uint16_t llc[288];
     uint16_t dc[32];
@@ -3424,13 +3425,15 @@ struct alignas(4) PackLds {
     uint32_t wbuf[PKW][PACK_WORDS];  // per wave: the bits of its 256 tokens of a round, zero between rounds
 };
 
+template <uint32_t PKT>
 __global__ __launch_bounds__(PKT) void k_pack(const uint8_t* __restrict__ in, uint32_t n,
                                               const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                               const BlockHeader* __restrict__ hdr, const BlockPlan* __restrict__ plan,
                                               const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ q13,
                                               uint32_t compat, uint32_t* __restrict__ out32, BlockTab tab,
                                               const uint32_t* __restrict__ ll_freq, const uint32_t* __restrict__ d_freq, uint32_t piece) {
-    __shared__ PackLds s;
+    constexpr uint32_t PKW = PKT / 64;
+    __shared__ PackLds<PKW> s;
     const uint32_t b = sc->nbcum[piece] + blockIdx.x / PSPLIT, part = blockIdx.x % PSPLIT, tid = threadIdx.x;
     if (b >= sc->nb || spec_failed(sc)) return;
     const uint32_t gtid = part * PKT + tid;  // a stored block's bytes are spread over all parts' threads
@@ -4036,6 +4039,15 @@ __global__ void k_gzip_frame(DevScalars* sc, uint8_t* out, const uint8_t* hdr, u
             hipLaunchKernelGGL((k_emit<MODE, false>), grid, dim3(256), 0, st, __VA_ARGS__);              \
         else                                                                                             \
             hipLaunchKernelGGL((k_emit<MODE, true>), grid, dim3(256), 0, st, __VA_ARGS__);               \
+    } while (0)
+// k_pack with workgroups of 1024 threads where the call has fewer parts than the device compute units (a part's rounds are
+// its time then: a 167 KB file 24.6 -> us), of MI355_PACK_THREADS otherwise (more workgroups a unit)
+#define MI355_LAUNCH_PACK(units, n_cu, st, ...)                                                              \
+    do {                                                                                                     \
+        if ((units) <= ((n_cu) ? (n_cu) : 256u))                                                             \
+            hipLaunchKernelGGL((k_pack<PKT_SMALL>), dim3(units), dim3(PKT_SMALL), 0, st, __VA_ARGS__);       \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_pack<PKT_LARGE>), dim3(units), dim3(PKT_LARGE), 0, st, __VA_ARGS__);       \
     } while (0)
 #include "deflate_host.inc"
 #include "deflate_shard.inc"
