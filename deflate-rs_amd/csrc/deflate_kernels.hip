@@ -2280,6 +2280,11 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
                            &s_np[wv], &s_exit[wv], k, given, lane);
 }
 
+// segment i was entered somewhere else than segment i - 1 was left, and segment i - 1 was not (a run's head)
+__device__ __forceinline__ bool spec_run_head(uint32_t i, uint32_t K, const uint32_t* E0, const uint32_t* Xs) {
+    if (i == 0 || i >= K || E0[i] == Xs[i - 1]) return false;
+    return i == 1 || E0[i - 1] == Xs[i - 2];
+}
 // k_spec_check: after the speculative k_emit, which segments were entered somewhere else than the segment before them was
 // left?  A bit per segment and a list (in no particular order; segment and the exit before it) for the repair; sc->n_fix counts them.
 // (lo: the first segment of the range looked at -- a multiple of 64 -- K its end)
@@ -2287,7 +2292,11 @@ __global__ __launch_bounds__(256) void k_spec_check(uint32_t K, const uint32_t* 
                                                     uint32_t* __restrict__ badmap, uint32_t* __restrict__ list, uint32_t* __restrict__ n_fix,
                                                     uint32_t lo) {
     const uint32_t i = lo + blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
+    // (listed: the FIRST of a run of such segments -- a periodic stretch of a few kilobytes fails at every boundary inside it, and
+    // only its first segment's predecessor was left where the check sees it: the repair's wave goes on through the rest of the
+    // run, hop by hop.  With a wave per failed boundary, each parsing from an exit that was itself wrong, a zero run of 1.5 KB
+    // somewhere in the input sent the whole call to the exact parse.)
+    const bool off = spec_run_head(i, K, E0, Xs);
     const uint64_t m = __builtin_amdgcn_ballot_w64(off);
     if (lane == 0) {
         badmap[(i >> 5)] = (uint32_t)m;
@@ -2588,7 +2597,7 @@ __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __rest
         for (uint32_t i0 = 0; i0 < SMALL_TAIL_SEGS; i0 += SMALL_FIX_T) {
             const uint32_t i = i0 + tid;
             if ((i & ~63u) >= K) break;  // (whole waves)
-            const bool off = i > 0 && i < K && E0[i] != Xs[i - 1];
+            const bool off = spec_run_head(i, K, E0, Xs);  // (the first of a run of them: k_spec_check)
             const uint64_t m = __builtin_amdgcn_ballot_w64(off);
             if (lane == 0) {
                 badmap[i >> 5] = (uint32_t)m;

@@ -166,10 +166,11 @@ def test_custom_options(da, ctx):
 
 
 def test_small_one_shot_calls_between_parse_and_histograms(da, ctx):
-    """One-shot calls of at most 1024 token segments (1 MiB) run the check of the segment chain, the scan of the token
-    counts, the dense token array and the block table as ONE workgroup (k_small_tail; the tokens are made dense in it up
-    to 256 segments): sizes on both sides of its two limits, data with many full blocks (their last tokens are read for the
-    Q1 / Q13 questions), data whose speculative parse fails (the exact parse takes the same kernel), every level."""
+    """One-shot calls of at most 1024 token segments (1 MiB) run everything between the speculative parse and the dense
+    tokens -- the check of the segment chain, the repair of the entries that fail it, the scan of the token counts, the
+    block table -- as ONE workgroup (k_small_fix), and pack their blocks with workgroups of 1024 threads: sizes on both
+    sides of the limit, data with many full blocks (their last tokens are read for the Q1 / Q13 questions), data whose
+    speculative entries need the repair, data whose speculation fails (the exact parse takes the same kernel), every level."""
     seg = 1024
     text = datagen.text_like(1100 * seg, 41)
     noise = datagen.rng_bytes(1100 * seg, 42)
@@ -184,6 +185,20 @@ def test_small_one_shot_calls_between_parse_and_histograms(da, ctx):
                  datagen.mixed(900 * seg, 44), datagen.rng_bytes(300, 45) * 800):
         for level in LV:
             agree(da, ctx, data, *LV[level])
+    # Periodic stretches of a few segments: inside one a run-up of 128 positions does not meet the true path, every boundary
+    # in it fails the check, and the repair's wave parses on from the stretch's first segment (a fresh context: one whose
+    # speculation failed a moment ago -- the zero fill above -- parses the exact way for a while)
+    gaps = (lambda i: bytes(1500), lambda i: bytes(3000), lambda i: bytes([97 + i % 5, 98, 99, 100 + i % 3, 101]) * 600,
+            lambda i: noise[i * 300:(i + 1) * 300] * 10)
+    for g, gap in enumerate(gaps):
+        data = b"".join(text[i * 7000:(i + 1) * 7000] + gap(i) for i in range(60))
+        for level in ("default", "fast"):
+            c2 = da.Context(0)
+            try:
+                info = agree(da, c2, data, *LV[level])
+                assert info["spec_repaired"] > 0 and info["spec_fallback"] == 0, (g, level, info["spec_repaired"], info["spec_fallback"])
+            finally:
+                c2.close()
     # a sync flush behind everything that was written (the block table's sync marker), raw and zlib
     import io
     for n in (5000, 200 * seg + 5, 600 * seg):
