@@ -459,7 +459,10 @@ def main(argv=None):
     cap = da.bound(size) + 8
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     ctx = da.Context(dev_index)
-    ctx.config(da.Context.CFG_STAGE_CLOCKS, 1)  # (kernel_ms and stage_ms come from the call's own events, whatever --size is)
+    try:
+        ctx.config(da.Context.CFG_STAGE_CLOCKS, 1)  # (kernel_ms and stage_ms come from the call's own events, whatever --size is)
+    except da.DeflateError:
+        pass  # (a library of before the key -- MI355_DEFLATE_LIB, an A/B run -- has the clocks on anyway)
     ctx.reserve(size + (shard.HISTORY + shard.LOOKAHEAD if world > 1 else 0))  # set-up, like the context itself
     stream = torch.cuda.current_stream().cuda_stream
     flush = shard.flush_mode_for(rank, world)

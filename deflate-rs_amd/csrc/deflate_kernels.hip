@@ -2047,209 +2047,13 @@ __device__ __forceinline__ void emit_wave(const uint8_t* __restrict__ in, uint32
                                           uint32_t lane) {
     constexpr bool SPEC = MODE == 1;
     constexpr uint32_t REG = EmitRows<MODE, STEPS>::REG;
-    for (uint32_t hop = 0;; hop++) {
-    // (runup0: the first segment has data in front of it as well -- a range of a sharded or long encode with its history --
-    // and finds its entry like the others; without it the first segment starts at the stream's true entry, position 0)
-    const uint32_t w0 = (SPEC && (k > 0 || runup0)) ? SPEC_W : 0u;
-    const uint64_t a0 = k * SEG;  // the segment proper: its tokens go to slot k of tokbuf
-    const uint64_t a = a0 - w0, b = a0 + SEG < n ? a0 + SEG : n;  // (everything below is relative to a: the start of the run-up)
-    const uint32_t len = (uint32_t)(b - a);
-    if (!STEPS) {   // (fetched together: a load per round of a loop is a memory latency per round)
-        uint16_t av[REG / 64];
-#pragma unroll
-        for (uint32_t q = 0; q < REG / 64; q++) av[q] = q * 64 + lane < len ? adv[(uint64_t)pos0 + a + q * 64 + lane] : (uint16_t)0;
-#pragma unroll
-        for (uint32_t q = 0; q < REG / 64; q++)
-            if (q * 64 + lane < len) A[q * 64 + lane] = av[q];
-    } else {
-        // The steps worked out here, from M (k_adv's lazy step without its loop; one end of the data, the full-budget table
-        // only -- the host sees to that): k_adv read M and wrote two bytes a position for this kernel to read again, a
-        // third of the parse stage's traffic.  (a) the wave's entries, sixteen bytes a lane at a time: their lengths go to
-        // LDS (where P will be), "too far" (lz77.rs:275-278), the one thing a step wants of a distance, into a bit each;
-        const uint32_t* const Mf = M + (uint64_t)pos0 + a;
-        const uint64_t there = (uint64_t)n_total + 64 - ((uint64_t)pos0 + a);  // (the table is padded by 64 entries)
-        const uint32_t avail = there > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)there;
-        const uint32_t endd = rel_end(sg, (uint64_t)pos0 + a, 0);
-        const bool al = (reinterpret_cast<uintptr_t>(Mf) & 15) == 0;  // (a segment starts at a multiple of 128 entries of a 256-byte aligned table)
-        uint32_t tf = 0;
-        uint4 ev[STEP_CHUNKS];
-#pragma unroll
-        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
-            const uint32_t r0 = 4 * (lane + 64 * c);
-            ev[c] = make_uint4(0, 0, 0, 0);
-            if (r0 < len + 12) {
-                if (al && r0 + 4 <= avail) {
-                    ev[c] = *reinterpret_cast<const uint4*>(Mf + r0);
-                } else {
-                    uint32_t t[4] = {0, 0, 0, 0};
-                    for (uint32_t i = 0; i < 4; i++)
-                        if (r0 + i < avail) t[i] = Mf[r0 + i];
-                    ev[c] = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-            }
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
-            const uint32_t r0 = 4 * (lane + 64 * c);
-            const uint32_t e[4] = {ev[c].x, ev[c].y, ev[c].z, ev[c].w};
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) tf |= (uint32_t)match_too_far(m_len(e[i]), m_dist(e[i])) << (4 * c + i);
-            *reinterpret_cast<uint2*>(P + r0) = make_uint2(m_len(e[0]) | (e[1] << 16), m_len(e[2]) | (e[3] << 16));
-        }
-        wave_lds_fence();
-        // (b) the steps of four positions from nine lengths (k_adv); a chain of more than four deferrals runs the step itself
-        const bool lazy = cfg.mode == MODE_LAZY;
-#pragma unroll
-        for (uint32_t c = 0; c < STEP_CHUNKS; c++) {
-            const uint32_t r0 = 4 * (lane + 64 * c);
-            if (r0 >= len) continue;
-            const uint2 w0 = *reinterpret_cast<const uint2*>(P + r0), w1 = *reinterpret_cast<const uint2*>(P + r0 + 4);
-            const uint32_t L[9] = {w0.x & 0xffffu, w0.x >> 16, w0.y & 0xffffu, w0.y >> 16,
-                                   w1.x & 0xffffu, w1.x >> 16, w1.y & 0xffffu, w1.y >> 16, (uint32_t)P[r0 + 8]};
-            uint32_t ups = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 8; i++) ups |= (uint32_t)(L[i] < cfg.lazy_lt && L[i + 1] > L[i]) << i;
-            const uint32_t room = endd > r0 + 3 ? endd - r0 - 3 : 0u;  // a + 1 + 2 < endd  for a = r0 + i:  i < endd - r0 - 3
-            ups &= room >= 8 ? 0xFFu : (1u << room) - 1u;
-            ups = lazy ? ups : 0u;  // lz77.rs:512-534: the greedy step takes what it finds
-            uint32_t st4[4];
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                const uint32_t run = (uint32_t)__builtin_ctz(~(ups >> q));
-                const bool ok = r0 + q + 2 < endd && L[q] >= MIN_MATCH && !((tf >> (4 * c + q)) & 1u);
-                const uint32_t Le = P[r0 + q + run];  // (q + run <= 8)
-                st4[q] = ok ? (run + Le) | (run << ADV_RUN_SHIFT) : 1u;
-                if (ok && q + run >= 8) {
-                    const TileM mf{Mf};
-                    st4[q] = adv_pack(parse_step(mf, mf, r0 + q, endd, cfg));
-                }
-            }
-            *reinterpret_cast<uint2*>(A + r0) = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));
-        }
-    }
-    wave_lds_fence();
-    // Four steps from every position (fewer where they leave the segment), straight from the steps: four dependent reads an
-    // entry, but the entries are independent of each other and go out to P, which nothing reads meanwhile -- a lane's eighteen
-    // chains run side by side.  (Before: two steps, then two of those in place, left to right, sixty-four entries at a time
-    // between two fences -- as many reads, and eighteen rounds one after the other: a fifth of the kernel.)
-#pragma unroll
-    for (uint32_t c = 0; c < REG / 64; c++) {
-        const uint32_t r = c * 64 + lane;
-        uint32_t t = r;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) t += t < len ? (uint32_t)(A[t < len ? t : 0u] & ADV_LEN_MASK) : 0u;
-        if (r < len) P[r] = (uint16_t)(t - r);
-    }
-    wave_lds_fence();
-    if (lane == 0) {
-        // the i-th recorded position is at least 4 i: its slot lies at or before the entry just read, and the
-        // chain only reads further right
-        uint32_t np = 0;
-        uint32_t j;
-        if (SPEC) {
-            // the run-up: to the first restart position in the segment -- four steps at a time while they stay in front of
-            // it, then single steps (single steps all the way were some twenty dependent LDS reads on one lane)
-            j = 0;
-            for (;;) {
-                const uint32_t t = j + P[j];
-                if (t >= w0) break;
-                j = t;
-            }
-            while (j < w0) j += A[j] & ADV_LEN_MASK;
-            E0[k] = (uint32_t)(a + j);
-        } else {
-            const uint64_t e = MODE == 2 ? (uint64_t)given : (uint64_t)E0[k];
-            if (MODE == 2) E0[k] = given;
-            j = e >= b ? len : (uint32_t)(e - a);
-        }
-        while (j < len) {
-            const uint32_t at = j;
-            j += P[at];
-            P[np++] = (uint16_t)at;
-        }
-        if (MODE != 0) Xs[k] = (uint32_t)(a + j);  // where the path leaves the segment
-        *exit_w = (uint32_t)(a + j);
-        *np_w = np;
-    }
-    wave_lds_fence();
-    const uint32_t np = *np_w;
-    uint32_t* out = tokbuf + a0;
-    // (32-bit positions relative to the first byte the wave holds: tables, input and the end of the data)
-    const uint64_t sbase = (uint64_t)pos0 + a;
-    const uint32_t* const Ms = M + sbase;
-    const uint32_t* const Mqs = (Mq ? Mq : M) + sbase;
-    const uint8_t* const ins = in + sbase;
-    const uint32_t one = sg.m == 1 ? rel_end(sg, sbase, 0) : 0u;
-    uint32_t running = 0;
-    for (uint32_t i0 = 0; i0 < np; i0 += 64) {
-        const uint32_t idx = i0 + lane;
-        const bool have = idx < np;
-        uint32_t nl[4], tm[4], ntok = 0;
-        uint32_t jp[4];  // (relative to the segment, like the tables below)
-        // What a step did is read off the entry k_adv filed for it (adv_pack: its length, its deferrals, the table of its
-        // match) instead of being worked out again from M: a length of 1 is a literal; otherwise the deferrals are literals
-        // and the match is the rest of the length at the distance of the entry behind them.  A lane's four positions come
-        // out of the lengths in LDS, so its four distances and first literal bytes are fetched together, one memory
-        // latency for the round (worked out step by step -- M at the position, behind it, and on while the chain went on --
-        // they were several in a row, under divergent branches).  MODE_RLE's distance is 1 (rle.rs:46-69).
-        uint32_t rel = have ? (uint32_t)P[idx] : len;
-        uint32_t ent[4], lb[4], ad[4];
-        const bool rle = cfg.mode == MODE_RLE;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool on = rel < len;
-            jp[q] = on ? rel : len;
-            ent[q] = 1u << 16;
-            lb[q] = ad[q] = 0;
-            if (on) {
-                const uint32_t w = A[rel];
-                ad[q] = w;
-                if (!rle) ent[q] = ((w >> ADV_FROMQ_SHIFT) ? Mqs : Ms)[rel + ((w >> ADV_RUN_SHIFT) & ADV_RUN_MASK)];  // (padded tables)
-                lb[q] = ins[rel];
-                rel += w & ADV_LEN_MASK;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t j = jp[q], adv_j = ad[q] & ADV_LEN_MASK, run = (ad[q] >> ADV_RUN_SHIFT) & ADV_RUN_MASK;
-            nl[q] = adv_j == 1 ? 1u : run;
-            tm[q] = adv_j > 1 ? tok_match(adv_j - run, m_dist(ent[q])) : 0u;  // (never 0 for a match: dist >= 1)
-            if (run == ADV_RUN_MANY) {  // more deferrals in a row than the entry holds: the step itself
-                const TileM m{Ms}, mq{Mqs};
-                const Step st = parse_step(m, mq, j, sg.m == 1 ? one : rel_end(sg, sbase, j), cfg);
-                nl[q] = st.nlit;
-                tm[q] = tok_match(st.mlen, st.mdist);
-            }
-            ntok += nl[q] + (tm[q] ? 1u : 0u);
-        }
-        uint32_t incl = ntok;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if (lane >= (uint32_t)off) incl += v;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        uint32_t* o = out + running + (incl - ntok);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (nl[q]) o[0] = tok_literal(lb[q]);
-            for (uint32_t x = 1; x < nl[q]; x++) o[x] = tok_literal(ins[jp[q] + x]);
-            o += nl[q];
-            if (tm[q]) *o++ = tm[q];
-        }
-        running += total;
-    }
-    if (lane == 0) cnt[k] = running;
-    if (MODE != 2) break;
-    // the repair goes on while the exit of the segment just parsed is not the entry the next one was parsed from
-    const uint32_t x = *exit_w;
-    wave_lds_fence();
-    k++;
-    if (k >= K || hop + 1 >= FIX_HOPS) break;
-    if ((badmap[k >> 5] >> (k & 31)) & 1u) break;  // (listed: another wave's)
-    if (E0[k] == x) break;                             // the paths have met
-    given = x;
-    }
+#define EMIT_NP (*np_w)
+#define EMIT_EXIT (*exit_w)
+#define EMIT_BADMAP badmap
+#include "emit_body.inc"
+#undef EMIT_NP
+#undef EMIT_EXIT
+#undef EMIT_BADMAP
 }
 
 // (STEPS: the wave works the restart steps out itself, from M -- adv is not read; else they come from k_adv / k_rle through adv)
@@ -2276,8 +2080,17 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
         k = fix.list[2 * k];
     }
     if (k >= K) return;  // whole wave; no workgroup barrier is used below
-    emit_wave<MODE, STEPS>(in, n, K, M, Mq, cfg, adv, E0, tokbuf, cnt, pos0, n_total, sg, Xs, fix.badmap, runup0, s_adv[wv], s_pp[wv],
-                           &s_np[wv], &s_exit[wv], k, given, lane);
+    constexpr bool SPEC = MODE == 1;
+    constexpr uint32_t REG = EmitRows<MODE, STEPS>::REG;
+    uint16_t* A = s_adv[wv];
+    uint16_t* P = s_pp[wv];
+#define EMIT_NP s_np[wv]
+#define EMIT_EXIT s_exit[wv]
+#define EMIT_BADMAP fix.badmap
+#include "emit_body.inc"
+#undef EMIT_NP
+#undef EMIT_EXIT
+#undef EMIT_BADMAP
 }
 
 // segment i was entered somewhere else than segment i - 1 was left, and segment i - 1 was not (a run's head)
