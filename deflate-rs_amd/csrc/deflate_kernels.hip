@@ -91,6 +91,8 @@ struct DevScalars {
     uint32_t crc;          // CRC-32 of the input (gzip trailer), XOR-accumulated by k_crc_fold
     uint64_t adler_a, adler_b;  // sums of the chunk contributions (k_adler_part)
     uint32_t n_fix[PIECES_MAX];    // segments whose speculative entry did not check out (k_spec_check), per piece
+    uint32_t q1_cancel;    // a small call's first pass: block 0 ended inside the first window and the hashes will be re-warmed (Q1) -- the
+                           // block stages of this pass have nothing to do (the host runs the call again; run_encode `speculate`)
     // A host call whose input is still arriving works on the stream piece by piece (deflate_host.inc run_streamed): what a
     // piece hands to the next one -- tokens and complete blocks so far; total_bits above is the bit position so far
     uint32_t Tcum[PIECES_MAX + 1];
@@ -112,7 +114,8 @@ struct DevState {
 };
 
 // (the kernels behind a speculative parse that failed its check have nothing to do: the host parses again)
-__device__ __forceinline__ bool spec_failed(const DevScalars* sc) { return reinterpret_cast<const DevState*>(sc)->spec_bad != 0; }
+// (... and so have the block stages of a first pass that will be run again with re-warmed hashes: q1_cancel)
+__device__ __forceinline__ bool spec_failed(const DevScalars* sc) { return (reinterpret_cast<const DevState*>(sc)->spec_bad | sc->q1_cancel) != 0; }
 
 constexpr uint32_t SEG = 1024;  // positions per level-0 segment
 #ifndef MI355_ADV_STRAIGHT
@@ -2093,6 +2096,23 @@ __global__ __launch_bounds__(256) void k_emit(const uint8_t* __restrict__ in, ui
 #undef EMIT_BADMAP
 }
 
+// Quirk Q1 (lz77.rs:628-638): block 0 holds 31744 tokens and its last token -- tk, at tp < WINDOW_SIZE -- leaves the encoder inside
+// the first window: two hashes are re-warmed at *wpos and the tables change.  One predicate for the host (which runs the call
+// again) and the device (which stops the first pass's block stages).
+__host__ __device__ inline bool q1_rewarm(uint32_t tk, uint64_t tp, uint32_t mode, uint64_t n, uint64_t* wpos) {
+    uint64_t lp;
+    if (mode == MODE_LAZY) {
+        lp = tp + 1;
+        if (tk >> 16)
+            *wpos = tp + tok_cover(tk);
+        else
+            *wpos = ((tp + 1) + 2 < n) ? tp + 2 : tp + 1;
+    } else {
+        lp = tp;
+        *wpos = tp + tok_cover(tk);
+    }
+    return lp < WINDOW_SIZE && *wpos <= WINDOW_SIZE;
+}
 // segment i was entered somewhere else than segment i - 1 was left, and segment i - 1 was not (a run's head)
 __device__ __forceinline__ bool spec_run_head(uint32_t i, uint32_t K, const uint32_t* E0, const uint32_t* Xs) {
     if (i == 0 || i >= K || E0[i] == Xs[i - 1]) return false;
@@ -2313,7 +2333,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
                                                       const uint32_t* __restrict__ E0, const uint32_t* __restrict__ tokbuf,
                                                       const uint32_t* __restrict__ dtok, DevScalars* sc,
                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ q13,
-                                                      BlockTab tab, Piece pc, const uint32_t* __restrict__ xs_last) {
+                                                      BlockTab tab, Piece pc, const uint32_t* __restrict__ xs_last, uint32_t q1_cancel) {
     // (a piece of a stream that is still arriving: the blocks that became complete with it, sc->nbcum[pc.p] .. sc->nb - 1)
     const uint32_t b = sc->nbcum[pc.p] + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b > nb_max) return;
@@ -2353,6 +2373,8 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
             sc->b0_full = 1;
             sc->b0_last_tok = tk;
             sc->b0_last_pos = tp;
+            uint64_t wpos;
+            if (q1_cancel && q1_rewarm(tk, tp, mode, n, &wpos)) sc->q1_cancel = 1;
         }
         if (tk >> 16) {  // lz77.rs:679-695
             uint64_t lp = (mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
@@ -2397,7 +2419,7 @@ __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __rest
                                                            uint32_t nb_max, uint32_t sync_final, uint32_t* __restrict__ spec_bad,
                                                            uint32_t* __restrict__ base, DevScalars* sc, uint32_t* __restrict__ tend,
                                                            uint32_t* __restrict__ pb, uint32_t* __restrict__ bstart,
-                                                           uint32_t* __restrict__ q13, BlockTab tab) {
+                                                           uint32_t* __restrict__ q13, BlockTab tab, uint32_t q1_cancel) {
     constexpr uint32_t ROW = EmitRows<2, STEPS>::ROW, NW = SMALL_FIX_T / 64;
     __shared__ __attribute__((aligned(8))) uint16_t s_adv[NW][ROW];
     __shared__ __attribute__((aligned(8))) uint16_t s_pp[NW][ROW];
@@ -2497,6 +2519,8 @@ __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __rest
                 sc->b0_full = 1;
                 sc->b0_last_tok = tk;
                 sc->b0_last_pos = tp;
+                uint64_t wpos;
+                if (q1_cancel && q1_rewarm(tk, tp, cfg.mode, n, &wpos)) sc->q1_cancel = 1;
             }
             if (tk >> 16) {  // lz77.rs:679-695
                 const uint64_t lp = (cfg.mode == MODE_LAZY) ? (uint64_t)tp + 1 : tp;
