@@ -1285,7 +1285,7 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
                                          const uint16_t* __restrict__ Sg, const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                          uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16, SegEnds sg,
                                          HashOverride ov, uint32_t split, uint32_t* __restrict__ Ms, uint32_t* __restrict__ Mqs,
-                                         uint32_t* __restrict__ sort_bad) {
+                                         uint32_t* __restrict__ sort_bad, const uint32_t pair = 2u) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
 #ifdef MI355_MATCH_STATS
     uint32_t m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
         uint32_t pxat = ~0u, pxm = 0, pxq = 0, pyat = ~0u, pym = 0, pyq = 0;
         for (;;) {
             uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&s_next, 2u);
+            if (lane == 0) b = atomicAdd(&s_next, pair);  // (pair == 1: a small call's waves take one batch each -- the second fibre stays empty)
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
             if (b >= b_hi) break;
             SwG<HAS_Q> sx, sy;
@@ -1426,7 +1426,7 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
             uint32_t lastx, lasty;
             const uint32_t front = b ? (uint32_t)own[(uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 64 - 1))] : 0u;
             const bool vx = set_up(win, sx, b, true, &srx, front, &lastx);
-            const bool vy = set_up(win, sy, b + 1, b + 1 < b_hi, &sry, lastx, &lasty);
+            const bool vy = set_up(win, sy, b + 1, pair == 2u && b + 1 < b_hi, &sry, lastx, &lasty);
             (void)lasty;
             M2_CNT(0, 2)
             M2_T(8)
@@ -1575,14 +1575,14 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                                 uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
                                                 SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
-                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
+                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad, uint32_t pair) {
     __shared__ __attribute__((aligned(256))) uint4 s_T[M3_TABLE_U4];
     __shared__ uint32_t s_next;
     const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
     if (MI355_SWZ_BANKS && __builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2]))
-        m3_epoch<HAS_Q, true>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+        m3_epoch<HAS_Q, true>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad, pair);
     else
-        m3_epoch<HAS_Q, false>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
+        m3_epoch<HAS_Q, false>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad, pair);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -151,7 +151,7 @@ const char* mi355_deflate_last_error(mi355_deflate_ctx* ctx);
  *   MI355_CFG_STAGE_CLOCKS  the per-stage clocks in mi355_deflate_info -- stage_ms, match_ms --: 2 (default) = for calls of 32 MiB or
  *                          more, 1 = for every call, 0 = never.  They are events between the kernels of a call, each 5.7 us of
  *                          idle queue -- a tenth of a 167 KB call; without them stage_ms and match_ms read 0 and total_ms is the
- *                          time from the call's first kernel to its last. */
+ *                          host's clock from the call's first launch to the return of its last wait. */
 #define MI355_CFG_RANGE_BYTES 1
 #define MI355_CFG_LONG_FROM 2
 #define MI355_CFG_SORT_RANKS 3
@@ -211,8 +211,8 @@ typedef struct {
     uint32_t passes;          /* 1, or 2 when Q1 forced a second pass */
     uint32_t spec_fallback;   /* 1: the speculative segment entries of the parse did not check out (long periodic data) and
                                  the call was parsed again the exact way -- same bytes, about a millisecond per 100 MB more */
-    float stage_ms[MI355_N_STAGES]; /* HIP-event time per stage, summed over passes */
-    float total_ms;                 /* first kernel enqueued .. last kernel done */
+    float stage_ms[MI355_N_STAGES]; /* HIP-event time per stage, summed over passes (0 without the stage clocks: MI355_CFG_STAGE_CLOCKS) */
+    float total_ms;                 /* first kernel enqueued .. last kernel done (without the stage clocks: the host's clock over the same) */
     uint32_t match_launches;        /* launches of the dominant kernel in this encode */
     float match_ms;                 /* their summed duration */
     uint32_t spec_repaired;         /* segments whose speculative entry was wrong and that were parsed again in place */

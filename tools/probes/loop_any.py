@@ -1,5 +1,5 @@
 """Development aid (GPU box): N device-resident encodes of a chosen input with the library MI355_DEFLATE_LIB names, nothing checked
--- for rocprofv3 over build variants.   loop_any.py <records96|records40|records256|text|dbrows|rows:WIDTH> <default|best|fast> [reps] [MB]"""
+-- for rocprofv3 over build variants.   loop_any.py <records96|records40|records256|text|dbrows|enwik|rows:WIDTH> <default|best|fast> [reps] [MB]"""
 import os, sys
 os.environ.setdefault("MI355_STAGE_CLOCKS", "1")  # (this aid reads the per-stage clocks: on for calls of every size)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,8 @@ if kind.startswith("rows:"):  # rows of one length throughout: rows:40
     cols = r.choice(np.arange(8, width), size=max(1, width // 8), replace=False)
     a[:, cols] = r.integers(0, 16, size=(rows, len(cols)), dtype=np.uint8)
     data = a.reshape(-1)[:int(mb * 1e6)].tobytes()
+elif kind == "enwik":  # the bench's text
+    data = datagen.text_like(int(mb * 1e6), 0x656E)
 else:
     sil = datagen.silesia_like(scale=0.5)
     off = {"text": 0, "records96": 58.3e6, "records40": 109.5e6, "records256": 115.7e6, "dbrows": 137.3e6}[kind]
