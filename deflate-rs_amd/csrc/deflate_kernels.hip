@@ -1280,12 +1280,13 @@ __device__ __forceinline__ uint32_t rel_end(const SegEnds& sg, uint64_t base, ui
     return e > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e;
 }
 // One epoch (or one part of it) by one workgroup: the body of both kernels below.  SWZ: the permuted table (PairWinT<true>).
-template <bool HAS_Q, bool SWZ>
+template <bool HAS_Q, bool SWZ, bool SINGLE = false>
 __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uint32_t e, const uint32_t part, const uint8_t* __restrict__ in, uint32_t n,
                                          const uint16_t* __restrict__ Sg, const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                          uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16, SegEnds sg,
                                          HashOverride ov, uint32_t split, uint32_t* __restrict__ Ms, uint32_t* __restrict__ Mqs,
-                                         uint32_t* __restrict__ sort_bad, const uint32_t pair = 2u) {
+                                         uint32_t* __restrict__ sort_bad) {
+    constexpr uint32_t pair = SINGLE ? 1u : 2u;  // batches a wave takes at a time (SINGLE: a small call, see walk_all)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
 #ifdef MI355_MATCH_STATS
     uint32_t m2c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1351,7 +1352,9 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
     uint32_t unordered = 0;
     // set a fibre up for batch b (all lanes call it: the lane masks it sets must be ballots of the whole wave)
     // (before0: the entry in front of the batch's first one, for the order check below)
-    auto set_up = [&](const auto& win, SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out, uint32_t before0, uint32_t* last_out) -> bool {
+    // (skip / budget / budget_q: a small call's second fibre walks the SAME batch from `skip` candidates down -- see walk_all)
+    auto set_up = [&](const auto& win, SwG<HAS_Q>& st, uint32_t b, bool have, uint32_t* srel_out, uint32_t before0, uint32_t* last_out,
+                      uint32_t skip, uint32_t budget, uint32_t budget_q) -> bool {
         const uint32_t j = b * 64 + lane;
         const bool valid = have && j < J;
         uint32_t raw = 0, srel = 0, ob = 0, pb0 = 0, pb1 = 0, prel = bias, nrel = bias;  // (a lane without a position: nothing to search)
@@ -1379,7 +1382,20 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
         const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)before0, (int)raw, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         unordered |= (valid && j > ob && before >= raw) ? 1u : 0u;
         *last_out = (uint32_t)__builtin_amdgcn_readlane((int)raw, 63);
-        (void)swg_setup(st, win, valid ? j : 0u, ob, pb0, pb1, prel, nrel, tbase, bias, checks, checks_q);
+        // (the candidates from rank skip + 1 on are those of the entry `skip` places down its bucket -- the same array, shifted --
+        // and where the own epoch's part of the bucket is shorter than that, what is left of `skip` comes off the previous epoch's)
+        uint32_t je = valid ? j : 0u, pe1 = pb1;
+        if (skip) {
+            const uint32_t n_own = je - ob;
+            if (n_own >= skip) {
+                je -= skip;
+            } else {
+                const uint32_t rest = skip - n_own, n_prev = pb1 - pb0;
+                je = ob;
+                pe1 = pb1 - (rest < n_prev ? rest : n_prev);
+            }
+        }
+        (void)swg_setup(st, win, je, ob, pb0, pe1, prel, nrel, tbase, bias, budget, budget_q);
         *srel_out = srel;
         return valid;
     };
@@ -1425,8 +1441,15 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
             // (the entry in front of the pair's first one: a scalar load -- b is the same for the whole wave)
             uint32_t lastx, lasty;
             const uint32_t front = b ? (uint32_t)own[(uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 64 - 1))] : 0u;
-            const bool vx = set_up(win, sx, b, true, &srx, front, &lastx);
-            const bool vy = set_up(win, sy, b + 1, pair == 2u && b + 1 < b_hi, &sry, lastx, &lasty);
+            // A small call (pair == 1: a batch a wave) gives its second fibre the far half of the SAME batch's candidates: what
+            // longest_match computes is a function of the candidate set (the longest common prefix, the nearest among equals:
+            // stages.h, the head of the sorted walk), so the first `half` candidates and the rest can be walked side by side
+            // and the far half's result taken only where it is strictly longer.  The quarter-budget result (checks >> 2 <=
+            // half) is the near half's.  A batch's time is its slowest lane's chain of step blocks: half as long this way.
+            const uint32_t half = (pair == 1u && checks >= 16u) ? checks / 2u : 0u;
+            const bool vx = set_up(win, sx, b, true, &srx, front, &lastx, 0u, half ? half : checks, checks_q);
+            const bool vy = half ? set_up(win, sy, b, true, &sry, front, &lasty, half, checks - half, 0u)
+                                 : set_up(win, sy, b + 1, pair == 2u && b + 1 < b_hi, &sry, lastx, &lasty, 0u, checks, checks_q);
             (void)lasty;
             M2_CNT(0, 2)
             M2_T(8)
@@ -1474,6 +1497,10 @@ __device__ __forceinline__ void m3_epoch(uint4* s_T, uint32_t& s_next, const uin
             swg_result(sy, &pym, &pyq);
             pxat = vx ? (Ms ? b * 64 + lane : srx) : ~0u;
             pyat = vy ? (Ms ? b * 64 + 64 + lane : sry) : ~0u;
+            if (half) {  // (the far half of the same positions: only a strictly longer match counts)
+                pxm = m_len(pym) > m_len(pxm) ? pym : pxm;
+                pyat = ~0u;
+            }
             M2_T(13)
         }
         if (pxat != ~0u) {
@@ -1570,19 +1597,19 @@ __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define MI355_M3_BOTH_UNITS 256
 #endif
 constexpr uint32_t M3_BOTH_UNITS = MI355_M3_BOTH_UNITS;
-template <bool HAS_Q>
+template <bool HAS_Q, bool SINGLE>
 __global__ __launch_bounds__(M3T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match3_both(const uint8_t* __restrict__ in, uint32_t n, const uint16_t* __restrict__ Sg,
                                                 const uint16_t* __restrict__ Bg, uint32_t* __restrict__ M,
                                                 uint32_t* __restrict__ Mq, uint32_t checks, uint32_t checks_q, int in_aligned16,
                                                 SegEnds sg, HashOverride ov, uint32_t e0, uint32_t split, uint32_t* __restrict__ Ms,
-                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad, uint32_t pair) {
+                                                uint32_t* __restrict__ Mqs, uint32_t* __restrict__ sort_bad) {
     __shared__ __attribute__((aligned(256))) uint4 s_T[M3_TABLE_U4];
     __shared__ uint32_t s_next;
     const uint32_t e = e0 + blockIdx.x / split, part = blockIdx.x % split;
     if (MI355_SWZ_BANKS && __builtin_amdgcn_readfirstlane((int)Bg[(size_t)e * BSTRIDE + WINDOW_SIZE + 2]))
-        m3_epoch<HAS_Q, true>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad, pair);
+        m3_epoch<HAS_Q, true, SINGLE>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
     else
-        m3_epoch<HAS_Q, false>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad, pair);
+        m3_epoch<HAS_Q, false, SINGLE>(s_T, s_next, e, part, in, n, Sg, Bg, M, Mq, checks, checks_q, in_aligned16, sg, ov, split, Ms, Mqs, sort_bad);
 }
 
 // ---------------------------------------------------------------------------------------------
