@@ -2426,7 +2426,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
 }
 
 // k_small_fix: what lies between the speculative parse and the dense tokens of a one-shot call (one segment end) of at most
-// 1024 token segments -- 1 MiB -- in ONE workgroup: k_spec_check, the repair (k_emit<2>), k_scan_a, k_scan_b and k_block_bounds
+// 2048 token segments -- 2 MiB -- in ONE workgroup (beyond that the block table, a wave a block, is better off with workgroups of its own): k_spec_check, the repair (k_emit<2>), k_scan_a, k_scan_b and k_block_bounds
 // were five launches of 4.5 us each, of one to four workgroups, with (on anything but periodic data) nothing to repair.
 //   1  which segments were entered somewhere else than the one before them was left: the bits and the list of k_spec_check;
 //   2  a wave per listed segment parses it again from where the segment before it was left (emit_wave<2>, as k_emit<2>);
@@ -2437,7 +2437,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
 #ifndef MI355_SMALL_TAIL
 #define MI355_SMALL_TAIL 1
 #endif
-constexpr uint32_t SMALL_TAIL_SEGS = 1024, SMALL_FIX_T = 512;
+constexpr uint32_t SMALL_TAIL_SEGS = 2048, SMALL_FIX_T = 512, SMALL_FIX_PER = SMALL_TAIL_SEGS / SMALL_FIX_T;  // (2 MiB; segments a thread scans)
 template <bool STEPS>
 __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                                            const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq, ParseCfg cfg,
@@ -2489,15 +2489,22 @@ __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __rest
         }
         __syncthreads();
     }
-    // ---- 3: the chain of entries and exits (k_scan_a), the scan of the token counts (k_scan_b): two segments a thread ----
-    const uint32_t i0 = 2 * tid, i1 = 2 * tid + 1;
-    uint32_t nbad = 0;
-    if (Xs) {
-        const bool off0 = i0 > 0 && i0 < K && E0[i0] != Xs[i0 - 1], off1 = i1 < K && E0[i1] != Xs[i1 - 1];
-        nbad = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off0)) + (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(off1));
+    // ---- 3: the chain of entries and exits (k_scan_a), the scan of the token counts (k_scan_b): a thread takes `per`
+    // consecutive segments (two for a call of up to 1 MiB, four for 2 MiB) ----
+    const uint32_t per = (K + SMALL_FIX_T - 1) / SMALL_FIX_T;  // <= SMALL_FIX_PER
+    const uint32_t s0 = tid * per;
+    uint32_t nbad = 0, v = 0;
+    uint32_t cs[SMALL_FIX_PER];
+#pragma unroll
+    for (uint32_t q = 0; q < SMALL_FIX_PER; q++) {
+        const uint32_t i = s0 + q;
+        const bool in = q < per && i < K;
+        if (Xs) nbad += (in && i > 0 && E0[i] != Xs[i - 1]) ? 1u : 0u;
+        cs[q] = in ? cnt[i] : 0u;
+        v += cs[q];
     }
-    const uint32_t c0 = i0 < K ? cnt[i0] : 0u, c1 = i1 < K ? cnt[i1] : 0u;
-    const uint32_t v = c0 + c1;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) nbad += __shfl_xor(nbad, off, 64);
     const uint32_t x = wave_incl_scan(v, lane);
     if (lane == 63) wtot[wv] = x;
     if (lane == 0) wbad[wv] = nbad;
@@ -2509,11 +2516,16 @@ __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __rest
         all += wtot[k];
         bad += wbad[k];
     }
-    const uint32_t mine = add + x - v;
-    s_base[i0] = mine;
-    s_base[i1] = mine + c0;
-    if (i0 < K) base[i0] = mine;
-    if (i1 < K) base[i1] = mine + c0;
+    uint32_t run = add + x - v;
+#pragma unroll
+    for (uint32_t q = 0; q < SMALL_FIX_PER; q++) {
+        const uint32_t i = s0 + q;
+        if (q < per && i < K) {
+            s_base[i] = run;
+            base[i] = run;
+        }
+        run += cs[q];
+    }
     const uint32_t T = T0 + all, nb = T / (uint32_t)MAX_BUFFER_LENGTH + 1u;
     if (tid == 0) {
         if (bad) atomicAdd(spec_bad, bad);

@@ -166,16 +166,16 @@ def test_custom_options(da, ctx):
 
 
 def test_small_one_shot_calls_between_parse_and_histograms(da, ctx):
-    """One-shot calls of at most 1024 token segments (1 MiB) run everything between the speculative parse and the dense
+    """One-shot calls of at most 2048 token segments (2 MiB) run everything between the speculative parse and the dense
     tokens -- the check of the segment chain, the repair of the entries that fail it, the scan of the token counts, the
     block table -- as ONE workgroup (k_small_fix), and pack their blocks with workgroups of 1024 threads: sizes on both
     sides of the limit, data with many full blocks (their last tokens are read for the Q1 / Q13 questions), data whose
     speculative entries need the repair, data whose speculation fails (the exact parse takes the same kernel), every level."""
     seg = 1024
-    text = datagen.text_like(1100 * seg, 41)
-    noise = datagen.rng_bytes(1100 * seg, 42)
+    text = datagen.text_like(2100 * seg, 41)
+    noise = datagen.rng_bytes(2100 * seg, 42)
     for n in (seg - 1, seg, seg + 1, 255 * seg + 7, 256 * seg, 256 * seg + 1, 700 * seg + 3, 1024 * seg - 1, 1024 * seg,
-              1024 * seg + 1):
+              1024 * seg + 1, 1500 * seg + 11, 2048 * seg - 1, 2048 * seg, 2048 * seg + 1):
         for level in LV:
             agree(da, ctx, text[:n], *LV[level])
             agree(da, ctx, noise[:n], *LV[level])

@@ -7,7 +7,7 @@ import datagen, deflate_amd as da
 ctx = da.Context(0)
 cases = [("pg11 167 KB", open(os.path.join(ROOT, "tests/golden/ref_inputs/pg11.txt"), "rb").read()),
          ("text 2 MB", datagen.text_like(2_000_000, 2)), ("text 16 MB", datagen.text_like(16_000_000, 3)),
-         ("random 1 MB (Q1)", datagen.rng_bytes(1_000_000, 4))]
+         ("random 1 MB (Q1)", datagen.rng_bytes(1_000_000, 4)), ("random 2 MB (Q1)", datagen.rng_bytes(2_000_000, 6))]
 for name, data in cases:
     n = len(data)
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
