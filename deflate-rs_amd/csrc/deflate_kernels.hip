@@ -2609,17 +2609,19 @@ constexpr uint32_t PSPLIT = MI355_PACK_SPLIT;
 constexpr uint32_t PQ = MAX_BUFFER_LENGTH / PSPLIT;  // tokens of a part
 static_assert(MAX_BUFFER_LENGTH % PSPLIT == 0, "parts of equal size");
 
-__global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
+// (HT threads a workgroup: 256, or 1024 for a call with fewer quarter blocks than compute units -- a quarter block in one round of loads)
+template <uint32_t HT>
+__global__ __launch_bounds__(HT) void k_block_hist(const uint32_t* __restrict__ dtok, const DevScalars* sc,
                                                     uint32_t* __restrict__ ll_freq, uint32_t* __restrict__ d_freq,
                                                     BlockTab tab, uint32_t piece, uint32_t* __restrict__ clear, uint32_t clear_words) {
     __shared__ uint32_t h[320];
     // (a small call's output buffer is cleared here -- k_pack ORs its bits in -- instead of by a fill of its own in front of
     // k_plan: two launches of the runtime on the way of a 0.3 ms call)
     if (clear)
-        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < clear_words; i += gridDim.x * 256) clear[i] = 0;
+        for (uint32_t i = blockIdx.x * HT + threadIdx.x; i < clear_words; i += gridDim.x * HT) clear[i] = 0;
     const uint32_t b = sc->nbcum[piece] + blockIdx.x / PSPLIT, q = blockIdx.x % PSPLIT;
     if (b >= sc->nb || spec_failed(sc)) return;
-    for (uint32_t i = threadIdx.x; i < 320; i += 256) h[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 320; i += HT) h[i] = 0;
     __syncthreads();
     const uint32_t nt = tab.nt[b];
     const uint64_t t0 = (uint64_t)tab.t0[b] + (uint64_t)q * PQ;
@@ -2627,13 +2629,13 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
     // (eight tokens a thread fetched together: one load per round in front of its LDS atomics was a memory latency per
     // round, thirty-one in a row -- the kernel's whole time)
     constexpr uint32_t HB = 8;
-    for (uint64_t tb = t0 + threadIdx.x; tb < t1; tb += 256 * HB) {
+    for (uint64_t tb = t0 + threadIdx.x; tb < t1; tb += HT * HB) {
         uint32_t tks[HB];
 #pragma unroll
-        for (uint32_t k = 0; k < HB; k++) tks[k] = tb + 256 * k < t1 ? dtok[tb + 256 * k] : 0u;
+        for (uint32_t k = 0; k < HB; k++) tks[k] = tb + HT * k < t1 ? dtok[tb + HT * k] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < HB; k++) {
-            if (tb + 256 * k >= t1) break;
+            if (tb + HT * k >= t1) break;
             const uint32_t tk = tks[k];
             if (tk >> 16) {
                 uint32_t c, eb, ev;
@@ -2648,8 +2650,8 @@ __global__ __launch_bounds__(256) void k_block_hist(const uint32_t* __restrict__
     }
     __syncthreads();
     const uint64_t slot = (uint64_t)b * PSPLIT + q;
-    for (uint32_t i = threadIdx.x; i < 288; i += 256) ll_freq[slot * 288 + i] = i < NUM_LL ? h[i] : 0;
-    for (uint32_t i = threadIdx.x; i < 32; i += 256) d_freq[slot * 32 + i] = i < NUM_DIST ? h[288 + i] : 0;
+    for (uint32_t i = threadIdx.x; i < 288; i += HT) ll_freq[slot * 288 + i] = i < NUM_LL ? h[i] : 0;
+    for (uint32_t i = threadIdx.x; i < 32; i += HT) d_freq[slot * 32 + i] = i < NUM_DIST ? h[288 + i] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3927,6 +3929,13 @@ __global__ void k_gzip_frame(DevScalars* sc, uint8_t* out, const uint8_t* hdr, u
     } while (0)
 // k_pack with workgroups of 1024 threads where the call has fewer parts than the device compute units (a part's rounds are
 // its time then: a 167 KB file 24.6 -> us), of MI355_PACK_THREADS otherwise (more workgroups a unit)
+#define MI355_LAUNCH_HIST(units, n_cu, st, ...)                                                              \
+    do {                                                                                                     \
+        if ((units) <= ((n_cu) ? (n_cu) : 256u))                                                             \
+            hipLaunchKernelGGL((k_block_hist<1024>), dim3(units), dim3(1024), 0, st, __VA_ARGS__);           \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_block_hist<256>), dim3(units), dim3(256), 0, st, __VA_ARGS__);             \
+    } while (0)
 #define MI355_LAUNCH_PACK(units, n_cu, st, ...)                                                              \
     do {                                                                                                     \
         if ((units) <= ((n_cu) ? (n_cu) : 256u))                                                             \
