@@ -600,9 +600,6 @@ struct SwG {
                                              // lane's segment and in its second one (both known at set-up)
     lane_flag walk, hq;
     lane_flag has2;  // a segment in the previous epoch's bucket is still to come
-    // the deep walk only (swg_group_deep): a SECOND probe -- the pair at the offset where the lane's last rejected candidate
-    // differed, as an address offset from the first probe's (dd <= 0) and its key -- and where the lane stopped in its last group
-    uint32_t dd, probe2, asel, back;
 };
 
 // Set a lane up for entry j of its epoch's array.  own_b0 = B_e[h]; [pb0, pb1) = the bucket in the previous
@@ -643,10 +640,6 @@ MI355_HD bool swg_setup(SwG<HAS_Q>& s, const W& w, uint32_t j, uint32_t own_b0, 
     s.lowa2 = tbase + (s.low << W::SH);
     w.load16(prel, s.p16);
     s.probe = w.key_at(tbase + (prel << W::SH));
-    s.dd = 0;  // (until a candidate has been rejected the second probe asks the first one's question again)
-    s.probe2 = s.probe;
-    s.asel = tbase;
-    s.back = 0;
     s.walk = lf_of(prel + 2 < nrel) & lf_of(checks > 0) & lf_of(n1 + n2 > 0);
     return search;
 }
@@ -700,9 +693,9 @@ MI355_HD void swg_group_ref(SwG<HAS_Q>& s, const W& w, int* d, uint32_t width) {
 // is read off the probe bytes; the others left at the end of their group).  Straight-line selects; only a match
 // longer than 16 bytes loops.
 // RUN1: the variant for inputs made of long runs of one byte (see the long compare below); chosen per launch.
-template <bool RUN1, bool DEEP, bool HAS_Q, class W>
-MI355_HD void swg_service_impl(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
-                               uint32_t asel, uint32_t ho) {
+template <bool RUN1, bool HAS_Q, class W>
+MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
+                          uint32_t asel, uint32_t ho) {
     // a probe that "hit" beyond the segment's last entry, or behind a candidate that is out of the window
     // (positions fall along a segment, so the hit's own address tells), is no hit
     // (one comparison per ballot: a ballot of `a && b` makes the compiler turn a lane mask into 0 / 1 values and back)
@@ -777,19 +770,6 @@ MI355_HD void swg_service_impl(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32
     }
     const lane_flag imp = hit & lf_of(len > s.bm1 + 1);  // matching.rs:149-156
     const uint32_t delta = lf_me(imp) ? len - 1 - s.bm1 : 0u;
-    if (DEEP) {
-        // The second probe.  A candidate that passed the probe and did not improve the match differs from the position at
-        // offset len <= bm1 + 1: candidates like it -- on record-like data every row that differs in the same field -- are asked
-        // about the pair (len - 1, len) as well from now on.  Every byte up to bm1 + 1 must match for a candidate to improve
-        // the match (matching.rs:149-156), so any pair inside that prefix passes whatever the reference's probe passes that
-        // matters: same result (the argument at the head of this section).  An improvement moves the first probe on by
-        // `delta` pairs; the second stays where it is.
-        const lane_flag rej = lf_and_not(hit, imp);
-        const uint32_t d2 = len ? len - 1u : 0u;
-        const uint32_t p2 = w.key_at(tbase + ((s.prel + d2) << W::SH));
-        s.probe2 = lf_me(rej) ? p2 : s.probe2;
-        s.dd = lf_me(rej) ? ((d2 - s.bm1) << W::SH) : s.dd - (delta << W::SH);
-    }
     s.bestd = lf_me(imp) ? s.prel - cpos : s.bestd;
     s.bm1 += delta;
     s.bb2 += delta << W::SH;
@@ -815,55 +795,6 @@ MI355_HD void swg_service_impl(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32
     // (the lanes that go on: those that still walk -- none of them was settled here -- and of the settled ones those with a
     // candidate left in their segment or a second segment to move to.  No "done" mask is kept.)
     s.walk = s.walk | resume | sw;
-}
-
-template <bool RUN1, bool HAS_Q, class W>
-MI355_HD void swg_service(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
-                          uint32_t asel, uint32_t ho) {
-    swg_service_impl<RUN1, false>(s, w, tbase, checks_q, dropped, dany, asel, ho);
-}
-template <bool RUN1, bool HAS_Q, class W>
-MI355_HD void swg_service_deep(SwG<HAS_Q>& s, const W& w, uint32_t tbase, uint32_t checks_q, lane_flag dropped, lane_flag dany,
-                               uint32_t asel, uint32_t ho) {
-    swg_service_impl<RUN1, true>(s, w, tbase, checks_q, dropped, dany, asel, ho);
-}
-
-// ---- the deep walk: data on which nearly every candidate passes the probe -----------------------------------------------
-// Rows of records that differ in a counter and a few narrow fields: every row of the window is a candidate of every
-// position behind it (hundreds at Compression::Best), one in sixteen passes the two-byte probe, and all but a few of those
-// fail inside the service's first sixteen bytes -- a batch of 64 positions then needs a service after nearly every group of
-// eight steps, and a service costs five groups.  The deep walk asks every candidate TWO questions, the reference's probe and
-// the pair where the lane's last rejected candidate differed (swg_service_impl<DEEP>), which passes one in 256, and the lanes
-// that leave a group wait for each other: one service settles a dozen of them.  k_match3 turns to it, batch by batch, when a
-// batch has needed more services than text ever does; one group of eight steps of a walking lane:
-template <bool HAS_Q, class W>
-MI355_HD void swg_group_deep(SwG<HAS_Q>& s, const W& w) {
-    if (!lf_me(s.walk)) return;
-    uint32_t e[8];
-    w.entries8(s.offb, e);  // e[i] = the entry `i` below the lane's next one (<< SH), as the step block reads them
-    const uint32_t key = s.probe | (s.probe2 << 16);
-    uint32_t k[8], a[8];
-#ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-#endif
-    for (int i = 0; i < 8; i++) {
-        a[i] = e[i] + s.bb2;
-        k[i] = w.key_at(a[i]) | (w.key_at(a[i] + s.dd) << 16);
-    }
-    uint32_t asel = a[0], back = 0;  // (back = 0: no hit; a hit at probe i: 16 - 2 i -- the first one wins)
-#ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-#endif
-    for (int i = 7; i >= 0; i--) {
-        const bool h = k[i] == key;
-        asel = h ? a[i] : asel;
-        back = h ? 16u - 2u * (uint32_t)i : back;
-    }
-    s.offb -= 16;
-    s.asel = asel;
-    s.back = back;
-    // no hit: on while the last candidate lay inside the window (matching.rs:102-106) and entries are left
-    s.walk = lf_of(back == 0 && a[7] >= s.lowa2 && (int32_t)s.offb >= (int32_t)s.endb);
 }
 
 template <bool HAS_Q>
