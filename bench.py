@@ -725,6 +725,41 @@ def main(argv=None):
                             "first byte in to last byte out; host_path bits: 1 pieces, 2 input by the context's host threads, 4 output by them")
             fast["runtime_copies"] = slow  # (MI355_CFG_HOST_BOUNCE = 0: what such a caller got before)
             res["value_host_api_pageable"] = fast
+        if world == 1 and not args.no_host_api:
+            # ... and what a SMALL call costs (the reference's own consumers -- a PNG's rows -- live there): the reference's
+            # fixture pg11.txt, 167 KB, resident and through the host-buffer call on pageable memory, wall clock, the
+            # context as a caller gets it (no per-stage events below 32 MiB: MI355_CFG_STAGE_CLOCKS)
+            pg = os.path.join(ROOT, "tests", "golden", "ref_inputs", "pg11.txt")
+            if os.path.exists(pg):
+                import ctypes
+                small = open(pg, "rb").read()
+                sctx = da.Context(dev_index)
+                s_in = torch.frombuffer(bytearray(small), dtype=torch.uint8).cuda()
+                s_cap = da.bound(len(small)) + 16
+                s_out = torch.empty(s_cap, dtype=torch.uint8, device="cuda")
+                h_in = (ctypes.c_uint8 * len(small)).from_buffer_copy(small)
+                h_o = (ctypes.c_uint8 * s_cap)()
+
+                def med(fn, reps=60):
+                    for _ in range(5):
+                        fn()
+                    ts = []
+                    for _ in range(reps):
+                        torch.cuda.synchronize()
+                        tc = time.perf_counter()
+                        fn()
+                        ts.append((time.perf_counter() - tc) * 1e3)
+                    ts.sort()
+                    return round(ts[len(ts) // 2], 4), round(ts[0], 4)
+                sn = [0]
+                r_med, r_min = med(lambda: sn.__setitem__(0, sctx.encode_device(s_in.data_ptr(), len(small), s_out.data_ptr(), s_cap, options)))
+                h_med, h_min = med(lambda: sctx.encode_host_ptr(ctypes.addressof(h_in), len(small), ctypes.addressof(h_o), s_cap, options))
+                res["small_call"] = {"input": "tests/golden/ref_inputs/pg11.txt", "bytes": len(small), "out_bytes": sn[0],
+                                     "resident_ms": {"median": r_med, "min": r_min},
+                                     "host_call_pageable_ms": {"median": h_med, "min": h_min},
+                                     "same_bytes": bool(bytes(h_o[:sn[0]]) == bytes(s_out[:sn[0]].cpu().numpy()))}
+                small_got = bytes(h_o[:sn[0]])
+                sctx.close()
         if world == 1 and not args.no_cpu_baseline:
             import oracle_binding as ob
             olvl = {"default": ob.DEFAULT, "best": ob.BEST, "fast": ob.FAST, "rle": ob.RLE,
@@ -737,6 +772,8 @@ def main(argv=None):
             got = bytes(d_out[: out_len[0]].cpu().numpy())
             res["ref_out_bytes"] = len(ref)
             res["bit_exact_vs_oracle"] = bool(got == ref)
+            if "small_call" in res:
+                res["small_call"]["bit_exact_vs_oracle"] = bool(small_got == ob.encode(small, level=olvl))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
