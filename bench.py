@@ -21,8 +21,9 @@ H2D and D2H inside the timed region), value_host_api_pageable (the same call on 
 bytearray in and out -- the context's host threads carry it; beside it the runtime's own copies, MI355_CFG_HOST_BOUNCE = 0), roofline.input_load (achieved HBM GB/s of the kernel that reads
 the input coalesced), roofline.lds_bank_conflict_rate of the match compare and roofline.valu_issue (wave
 instructions per input byte and the share of the SIMDs' cycles they take: what the dominant kernel is bound
-by; both from the committed PMC file),
-cpu_baseline as the median of five runs with its all-cores and zlib companions.
+by; from counters taken in the run, else from the committed PMC file),
+small_call (the reference's 167 KB fixture pg11.txt: wall clock of one resident call and of one host-buffer call on pageable memory,
+against the oracle), cpu_baseline as the median of five runs with its all-cores and zlib companions.
 """
 import argparse
 import json
