@@ -729,7 +729,7 @@ def main(argv=None):
         if world == 1 and not args.no_host_api:
             # ... and what a SMALL call costs (the reference's own consumers -- a PNG's rows -- live there): the reference's
             # fixture pg11.txt, 167 KB, resident and through the host-buffer call on pageable memory, wall clock, the
-            # context as a caller gets it (no per-stage events below 32 MiB: MI355_CFG_STAGE_CLOCKS)
+            # context as a caller gets it (no per-stage events: MI355_CFG_STAGE_CLOCKS)
             pg = os.path.join(ROOT, "tests", "golden", "ref_inputs", "pg11.txt")
             if os.path.exists(pg):
                 import ctypes

@@ -208,14 +208,17 @@ def test_small_one_shot_calls_between_parse_and_histograms(da, ctx):
 
 
 def test_stage_clocks_are_optional(da):
-    """mi355_deflate_info's per-stage clocks are events between the kernels of a call (5.7 us of idle queue each): calls below
-    32 MiB run without them unless MI355_CFG_STAGE_CLOCKS asks -- stage_ms and match_ms then read 0, total_ms is the host's
-    clock -- and the bytes are the same either way."""
+    """mi355_deflate_info's per-stage clocks are events between the kernels of a call (5.7 us of idle queue each): a call runs
+    without them unless MI355_CFG_STAGE_CLOCKS asks (1: every call, 2: calls of 32 MiB or more) -- stage_ms and match_ms then
+    read 0, total_ms is the host's clock -- and the bytes are the same either way."""
     c = da.Context(0)
     try:
         data = open(os.path.join(FIX, "pg11.txt"), "rb").read()
         ref = ob.encode(data, level=ob.DEFAULT)
         seen = {}
+        assert c.encode(data, da.Compression.Default) == ref  # (as a context comes: none)
+        i = c.info()
+        assert i["total_ms"] > 0 and i["match_ms"] == 0.0 and sum(i["stage_ms"].values()) == 0.0
         for mode in (2, 0, 1, 2):
             c.config(da.Context.CFG_STAGE_CLOCKS, mode)
             assert c.encode(data, da.Compression.Default) == ref
@@ -224,7 +227,7 @@ def test_stage_clocks_are_optional(da):
             seen[mode] = (i["match_ms"], sum(i["stage_ms"].values()))
         assert seen[0] == (0.0, 0.0) and seen[2] == (0.0, 0.0)
         assert seen[1][0] > 0 and seen[1][1] > 0
-        big = datagen.text_like(40 << 20, 77)  # (from 32 MiB on the default has them)
+        big = datagen.text_like(40 << 20, 77)  # (mode 2: from 32 MiB on)
         c.config(da.Context.CFG_STAGE_CLOCKS, 2)
         out = _encode_resident(da, c, big, da.Compression.Fast)  # (a host call of this size is worked on in pieces, which have clocks of their own)
         assert c.info()["match_ms"] > 0
