@@ -22,7 +22,8 @@ bytearray in and out -- the context's host threads carry it; beside it the runti
 the input coalesced), roofline.lds_bank_conflict_rate of the match compare and roofline.valu_issue (wave
 instructions per input byte and the share of the SIMDs' cycles they take: what the dominant kernel is bound
 by; from counters taken in the run, else from the committed PMC file),
-small_call (the reference's 167 KB fixture pg11.txt: wall clock of one resident call and of one host-buffer call on pageable memory,
+value_as_called (the timed steps once more as a caller's context runs them: without the per-stage clocks this bench asks for -- five
+events, 29 us of idle queue, in every timed step), small_call (the reference's 167 KB fixture pg11.txt: wall clock of one resident call and of one host-buffer call on pageable memory,
 against the oracle), cpu_baseline as the median of five runs with its all-cores and zlib companions.
 """
 import argparse
@@ -550,6 +551,22 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # (N = 1: the same steps once more as a caller's context runs them -- without the per-stage clocks this bench asks for, which
+    # are five events, 29 us of idle queue, in every step above: value_as_called)
+    elapsed_plain = None
+    if world == 1:
+        try:
+            ctx.config(da.Context.CFG_STAGE_CLOCKS, 0)
+            step(False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(False)
+            torch.cuda.synchronize()
+            elapsed_plain = time.perf_counter() - t1
+            ctx.config(da.Context.CFG_STAGE_CLOCKS, 1)
+        except da.DeflateError:
+            elapsed_plain = None
     p1_trace = None
     rccl_ranks = 0
     if shard_mode == "p1":  # one more step, untimed, with a device synchronisation after every phase
@@ -652,6 +669,11 @@ def main(argv=None):
             "step_ms_events": {"min": round(min(gpu_ms), 3), "median": round(sorted(gpu_ms)[len(gpu_ms) // 2], 3),
                                "max": round(max(gpu_ms), 3), "n": len(gpu_ms)},
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            # the same steps as a caller's context runs them: without the per-stage clocks (five events in every step above)
+            "value_as_called": ({"value": round(size * args.steps / elapsed_plain / 1e6, 2), "unit": "MB/s",
+                                 "ms_per_step": round(elapsed_plain * 1e3 / args.steps, 3),
+                                 "what": "the timed steps once more with MI355_CFG_STAGE_CLOCKS = 0, a context's default"}
+                                if elapsed_plain else None),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(mm, 3), "algorithmic_bytes_per_launch": algo_bytes,
