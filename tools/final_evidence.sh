@@ -28,6 +28,7 @@ timeout -s KILL 900 python tools/config5_8gib.py --virtual 8 2>/dev/null | tail 
 timeout -s KILL 600 python bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_300_steps.json; python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_bench_300_steps.json')); print('300 steps:', d['value'], d['ms_per_step'], d['step_ms_events'], d['value_host_api'], d['value_host_api_pageable'])"
 # the fuzzers, smoke() and the multi-GPU self-check
+set +x
 (echo "# the fuzzers, smoke() and tools/multi_selfcheck.py on the round's final tree (MI355X box)"
  timeout -s KILL 900 python tools/fuzz_gpu.py 2000 60000 2>&1 | tail -1
  timeout -s KILL 600 python tools/fuzz_flush_gaps.py 300 1 2>&1 | tail -1
@@ -37,3 +38,4 @@ import json; d=json.load(open('gpurun_out/${TAG}_bench_300_steps.json')); print(
  timeout -s KILL 200 python tools/multi_selfcheck.py 2>&1 | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('multi_selfcheck: ok=%s devices=%d cases=%d all same=%s (%.1f s)' % (d['ok'], d['devices'], len(d['cases']), all(c['same'] for c in d['cases']), d['seconds']))"
  timeout -s KILL 600 python tools/fuzz_pageable.py 2>&1 | tail -1) > gpurun_out/${TAG}_fuzz_round_end.txt 2>&1; cat gpurun_out/${TAG}_fuzz_round_end.txt
+set -x
