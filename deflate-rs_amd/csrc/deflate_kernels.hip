@@ -2297,7 +2297,13 @@ __device__ uint32_t token_start(uint32_t t, uint32_t K, const uint32_t* base, co
     const uint32_t m = t - base[lo];
     const uint32_t* tk = tokbuf + (uint64_t)lo * SEG;
     uint32_t cov = 0;
-    for (uint32_t i = lane; i < m; i += 64) cov += tok_cover(tk[i]);
+    // (a segment's tokens before t -- up to 1023 on noise --, fetched together: a load a round was a memory latency a round,
+    // sixteen in a row where every byte is a token)
+    uint32_t tv[SEG / 64];
+#pragma unroll
+    for (uint32_t r = 0; r < SEG / 64; r++) tv[r] = lane + 64 * r < m ? tk[lane + 64 * r] : 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < SEG / 64; r++) cov += lane + 64 * r < m ? tok_cover(tv[r]) : 0u;
 #pragma unroll
     for (int off = 32; off; off >>= 1) cov += __shfl_xor(cov, off, 64);
     return E0[lo] + cov;
@@ -2437,7 +2443,10 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t K, ui
 #ifndef MI355_SMALL_TAIL
 #define MI355_SMALL_TAIL 1
 #endif
-constexpr uint32_t SMALL_TAIL_SEGS = 2048, SMALL_FIX_T = 512, SMALL_FIX_PER = SMALL_TAIL_SEGS / SMALL_FIX_T;  // (2 MiB; segments a thread scans)
+#ifndef MI355_SMALL_SEGS
+#define MI355_SMALL_SEGS 2048
+#endif
+constexpr uint32_t SMALL_TAIL_SEGS = MI355_SMALL_SEGS, SMALL_FIX_T = 512, SMALL_FIX_PER = SMALL_TAIL_SEGS / SMALL_FIX_T;  // (2 MiB; segments a thread scans)
 template <bool STEPS>
 __global__ __launch_bounds__(SMALL_FIX_T) void k_small_fix(const uint8_t* __restrict__ in, uint32_t n, uint32_t K,
                                                            const uint32_t* __restrict__ M, const uint32_t* __restrict__ Mq, ParseCfg cfg,
