@@ -81,7 +81,8 @@ void stage_match(Sim& s) {
     if (s.cfg.checks == 0) return;
     HostWin w{s.in.data(), s.link.data()};
     uint32_t cq = s.cfg.use_quarter ? (s.cfg.checks >> 2) : 0;
-    if (g_multi == 6 || g_multi == 7) {
+    if (g_multi == 6 || g_multi == 7 || g_multi == 8) {
+        // (8: a small call's walk -- the near half of a position's candidates and the far half walked apart, m3_epoch<.., SINGLE>)
         // the k_sort + k_match3 formulation: epochs sorted by (hash, position), lanes walk their bucket's
         // entries (stages.h SwG); groups of steps and services alternate as on the GPU (7: the RUN1 service)
         const uint32_t W = WINDOW_SIZE;
@@ -135,6 +136,9 @@ void stage_match(Sim& s) {
                         return i < np ? 2u * ps[i] : 0u;
                     }
                 };
+                // (skip / budget / budget_q: as k_match3's set_up -- the candidates from rank skip + 1 on are those of the entry
+                // `skip` places down its bucket, and what the own epoch's part is short of comes off the previous epoch's)
+                uint32_t skip = 0, budget = s.cfg.checks, budget_q = cq;
                 auto run6 = [&](auto& ln, auto pw) {
                     pw.d = s.in.data() + wbase;
                     pw.nb = (uint64_t)s.in.size() - wbase;
@@ -142,7 +146,18 @@ void stage_match(Sim& s) {
                     pw.cs = curS.data();
                     pw.np = (uint32_t)prevS.size();
                     pw.nc = (uint32_t)curS.size();
-                    (void)swg_setup(ln, pw, j, curB[h], pb0, pb1, prel, nrel, 0u, bias, s.cfg.checks, cq);
+                    uint32_t je = j, pe1 = pb1;
+                    if (skip) {
+                        const uint32_t n_own = je - curB[h];
+                        if (n_own >= skip) {
+                            je -= skip;
+                        } else {
+                            const uint32_t rest = skip - n_own, n_prev = pb1 - pb0;
+                            je = curB[h];
+                            pe1 = pb1 - (rest < n_prev ? rest : n_prev);
+                        }
+                    }
+                    (void)swg_setup(ln, pw, je, curB[h], pb0, pe1, prel, nrel, 0u, bias, budget, budget_q);
                     const uint32_t width = (j & 4) ? 8u : 4u;  // (groups of four and of eight steps)
                     lane_flag dropped = (j % 3) ? swg_first(ln, pw, width) : lf_of(false);  // (with and without the short cut)
                     int d = dropped ? 0 : -1;
@@ -164,12 +179,29 @@ void stage_match(Sim& s) {
                     }
                     swg_result(ln, &m, &mq);
                 };
-                if (hasq) {
-                    SwG<true> ln;
-                    run6(ln, PWin());
+                auto run_one = [&]() {
+                    if (hasq) {
+                        SwG<true> ln;
+                        run6(ln, PWin());
+                    } else {
+                        SwG<false> ln;
+                        run6(ln, PWin());
+                    }
+                };
+                const uint32_t half = (g_multi == 8 && s.cfg.checks >= 16) ? s.cfg.checks / 2 : 0;
+                if (half) {
+                    // the near half (it also has the quarter-budget result), then the far half: only a strictly longer match counts
+                    budget = half;
+                    run_one();
+                    const uint32_t mx = m, mqx = mq;
+                    skip = half;
+                    budget = s.cfg.checks - half;
+                    budget_q = 0;
+                    run_one();
+                    m = m_len(m) > m_len(mx) ? m : mx;
+                    mq = mqx;
                 } else {
-                    SwG<false> ln;
-                    run6(ln, PWin());
+                    run_one();
                 }
                 s.M[E + r] = m;
                 s.Mq[E + r] = mq;

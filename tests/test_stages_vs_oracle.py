@@ -158,16 +158,17 @@ def test_q13_stored_after_slide_is_replicated():
 
 
 # The formulations of the chain walk in stages.h (single, multi-chain, parked, the pair-table form of k_match3 = mode 6, with its
-# run-of-one-byte service = mode 7) must give the
+# run-of-one-byte service = mode 7, with a position's candidates walked as a near and a far half -- a small call's walk, where the far
+# half's match counts only if strictly longer and the quarter-budget result is the near half's = mode 8) must give the
 # same match table and the same stream; mode 3 additionally cuts every compare short so that the
 # "stay parked, continue at the next service" path of the GPU policy is exercised.
-@pytest.mark.parametrize("mode", [1, 2, 3, 6, 7])
+@pytest.mark.parametrize("mode", [1, 2, 3, 6, 7, 8])
 def test_match_walk_formulations_agree(mode):
     cases = [datagen.text_like(200000, 3), datagen.mixed(150000, 5), datagen.rng_bytes(70000, 2), bytes(70000),
              b"abcabcabcabc", (datagen.rng_bytes(300, 5) * 400)]
     try:
         for data in cases:
-            for checks in (1, 7, 128, 1768):
+            for checks in (1, 7, 16, 17, 128, 1768):
                 hs.use_multi(0)
                 a = hs.match_table(data, checks)
                 hs.use_multi(mode)
